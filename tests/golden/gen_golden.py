@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE implementation (runs only where
+/root/reference exists, i.e. in the build container -- never on the GPU box).
+
+The reference's Triton kernels are executed unmodified on CPU with TRITON_INTERPRET=1;
+its modules are loaded by file path because `import sageattention` needs the compiled
+CUDA `_fused` extension (sageattention/quant.py:20).  The host glue of
+`sageattn_qk_int8_pv_fp16_triton` / `sageattn_varlen` (core.py:260-331, :399-448: pad,
+K mean, v->fp16, LSE fix-up) asserts `q.is_cuda`, so those ~40 lines are re-stated here
+line for line around the reference kernels.
+
+    TRITON_INTERPRET=1 python tests/golden/gen_golden.py
+
+writes tests/golden/*.npz (inputs + reference outputs, fp16/bf16 as uint16 bit patterns).
+"""
+import importlib.util
+import os
+import sys
+
+os.environ["TRITON_INTERPRET"] = "1"
+import numpy as np
+import torch
+
+REF = "/root/reference/sageattention/triton"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+quant_pb = _load("quant_per_block")
+quant_pb_varlen = _load("quant_per_block_varlen")
+quant_pt = _load("quant_per_thread")
+attn_nc = _load("attn_qk_int8_per_block")
+attn_c = _load("attn_qk_int8_per_block_causal")
+attn_nc_varlen = _load("attn_qk_int8_block_varlen")
+attn_c_varlen = _load("attn_qk_int8_per_block_causal_varlen")
+
+
+def bits(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def ref_dense(q, k, v, is_causal, sm_scale=None, smooth_k=True, return_lse=True):
+    """core.py:242-331 with tensor_layout="HND", quantization_backend="triton"."""
+    dtype = q.dtype
+    head_dim_og = q.size(-1)
+    if head_dim_og < 64:
+        q, k, v = (torch.nn.functional.pad(t, (0, 64 - head_dim_og)) for t in (q, k, v))
+    elif 64 < head_dim_og < 128:
+        q, k, v = (torch.nn.functional.pad(t, (0, 128 - head_dim_og)) for t in (q, k, v))
+    km = k.mean(dim=2, keepdim=True) if smooth_k else None
+    lse_correction = None
+    if smooth_k and return_lse:
+        g = q.size(1) // k.size(1)
+        kmb = torch.repeat_interleave(km, g, dim=1) if g > 1 else km
+        lse_correction = torch.matmul(q, kmb.transpose(2, 3)).squeeze(-1).to(torch.float32)
+    if dtype == torch.bfloat16:
+        v = v.to(torch.float16)
+    if sm_scale is None:
+        sm_scale = 1.0 / (head_dim_og ** 0.5)
+    q_int8, q_scale, k_int8, k_scale = quant_pb.per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout="HND")
+    if is_causal:
+        o, lse = attn_c.forward(q_int8, k_int8, v, q_scale, k_scale, tensor_layout="HND", output_dtype=dtype, return_lse=return_lse)
+    else:
+        o, lse = attn_nc.forward(q_int8, k_int8, v, q_scale, k_scale, tensor_layout="HND", output_dtype=dtype, return_lse=return_lse)
+    o = o[..., :head_dim_og]
+    if return_lse:
+        lse = lse / 1.44269504 + lse_correction * sm_scale if smooth_k else lse / 1.44269504
+    return o, lse, dict(q_int8=q_int8, q_scale=q_scale, k_int8=k_int8, k_scale=k_scale, km=km)
+
+
+def ref_varlen(q, k, v, cu_q, cu_k, max_q, max_k, is_causal, sm_scale=None, smooth_k=True):
+    """core.py:399-448."""
+    dtype = q.dtype
+    head_dim_og = q.size(-1)
+    if dtype == torch.bfloat16:
+        v = v.to(torch.float16)
+    if smooth_k:
+        km = k.mean(dim=0, keepdim=True)
+        k = k - km
+    if sm_scale is None:
+        sm_scale = 1.0 / (head_dim_og ** 0.5)
+    q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = quant_pb_varlen.per_block_int8(q, k, cu_q, cu_k, max_q, max_k, sm_scale=sm_scale)
+    fwd = attn_c_varlen.forward if is_causal else attn_nc_varlen.forward
+    o = fwd(q_int8, k_int8, v, cu_q, cu_k, max_q, q_scale, k_scale, cu_qs, cu_ks, output_dtype=dtype)
+    return o, dict(q_int8=q_int8, q_scale=q_scale, k_int8=k_int8, k_scale=k_scale, cu_qs=cu_qs, cu_ks=cu_ks)
+
+
+def sdpa_f32(q, k, v, is_causal, sm_scale=None):
+    qf, kf, vf = q.float(), k.float(), v.float()
+    g = q.size(1) // k.size(1)
+    if g > 1:
+        kf, vf = kf.repeat_interleave(g, 1), vf.repeat_interleave(g, 1)
+    return torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=is_causal, scale=sm_scale)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def dense_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, causal, kbias=0.0, seed=0):
+    torch.manual_seed(seed)
+    q = torch.randn(B, Hq, Lq, D).to(dtype)
+    k = (torch.randn(B, Hkv, Lk, D) + kbias * torch.randn(1, Hkv, 1, D)).to(dtype)
+    v = torch.randn(B, Hkv, Lk, D).to(dtype)
+    o, lse, aux = ref_dense(q, k, v, causal)
+    truth = sdpa_f32(q, k, v, causal) if Lq == Lk or not causal else None
+    arrs = dict(q=bits(q), k=bits(k), v=bits(v), o=bits(o), lse=lse.numpy(),
+                q_int8=aux["q_int8"].numpy(), q_scale=aux["q_scale"].numpy(),
+                k_int8=aux["k_int8"].numpy(), k_scale=aux["k_scale"].numpy(), km=bits(aux["km"]),
+                meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, int(causal)], dtype=np.int64))
+    if truth is not None:
+        cos = torch.nn.functional.cosine_similarity(o.float().flatten(), truth.flatten(), dim=0).item()
+        rmse = (o.float() - truth).pow(2).mean().sqrt().item()
+        print(f"  {name}: reference vs fp32 SDPA cos={cos:.6f} rmse={rmse:.2e}")
+    save(name, **arrs)
+
+
+def varlen_case(name, lens, Hq, Hkv, D, dtype, causal, seed=0):
+    torch.manual_seed(seed)
+    total = sum(lens)
+    q = torch.randn(total, Hq, D).to(dtype)
+    k = (torch.randn(total, Hkv, D) + 1.5 * torch.randn(1, Hkv, D)).to(dtype)
+    v = torch.randn(total, Hkv, D).to(dtype)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    o, aux = ref_varlen(q, k, v, cu, cu, max(lens), max(lens), causal)
+    save(name, q=bits(q), k=bits(k), v=bits(v), o=bits(o), cu=cu.numpy(),
+         q_int8=aux["q_int8"].numpy(), q_scale=aux["q_scale"].numpy(),
+         k_int8=aux["k_int8"].numpy(), k_scale=aux["k_scale"].numpy(),
+         cu_qs=aux["cu_qs"].numpy(), cu_ks=aux["cu_ks"].numpy(),
+         meta=np.array([len(lens), Hq, Hkv, total, total, D, 0 if dtype == torch.float16 else 1, int(causal)], dtype=np.int64))
+
+
+def per_thread_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, seed=0):
+    torch.manual_seed(seed)
+    q = torch.randn(B, Hq, Lq, D).to(dtype)
+    k = (torch.randn(B, Hkv, Lk, D) + 2.0).to(dtype)
+    km = k.mean(dim=2, keepdim=True)
+    q8, qs, k8, ks = quant_pt.per_thread_int8(q, k, km, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64)
+    save(name, q=bits(q), k=bits(k), km=bits(km), q_int8=q8.numpy(), q_scale=qs.numpy(), k_int8=k8.numpy(), k_scale=ks.numpy(),
+         meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not present; golden vectors can only be generated in the build container")
+    f16, bf16 = torch.float16, torch.bfloat16
+    dense_case("c1_b1h4n512d64_f16", 1, 4, 4, 512, 512, 64, f16, False)             # BASELINE.json configs[0]
+    dense_case("gqa_causal_n300d128_bf16", 1, 4, 2, 300, 300, 128, bf16, True, kbias=2.0, seed=1)
+    dense_case("cross_lq200_lk333_d64_f16", 2, 2, 2, 200, 333, 64, f16, False, kbias=1.0, seed=2)
+    dense_case("causal_n384d128_f16", 1, 2, 2, 384, 384, 128, f16, True, seed=3)
+    dense_case("pad_d96_n160_f16", 1, 2, 1, 160, 160, 96, f16, False, seed=4)
+    varlen_case("varlen_nc_d64_f16", [100, 257, 64], 4, 2, 64, f16, False, seed=5)
+    varlen_case("varlen_c_d64_f16", [100, 257, 64], 4, 2, 64, f16, True, seed=5)
+    varlen_case("varlen_c_d128_bf16", [130, 64, 300], 4, 1, 128, bf16, True, seed=6)
+    per_thread_case("per_thread_quant_d128_f16", 1, 2, 1, 200, 150, 128, f16, seed=7)
