@@ -1,0 +1,179 @@
+/*
+ * sage_gfx950.h -- C ABI of libsage_gfx950.so: SageAttention's quantized fused-attention hot
+ * path for AMD MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one (or a family) of the reference's
+ * native ops -- the pybind11 functions behind `sageattention._fused` and
+ * `sageattention._qattn_sm80/_sm89/_sm90` -- cited per function as file:line relative to the
+ * thu-ml/SageAttention tree.  The contract mirrors theirs:
+ *   - the CALLER owns every buffer (outputs are pre-allocated, the library only writes into
+ *     them; reference: `mutates_args=("output",)`, sageattention/sm80_compile.py:5);
+ *   - the library keeps no state, allocates nothing, and is re-entrant; work is enqueued on the
+ *     HIP stream passed as `stream` (a hipStream_t; NULL = the null stream) and the call returns
+ *     without synchronising;
+ *   - integer encodings follow the reference's op boundary: tensor dtype 0 = fp16, 1 = bf16;
+ *     `qk_quant_gran` 2 = per_warp, 3 = per_thread (core.py:556-559), plus 1 = per_block
+ *     (the Triton path's granularity);
+ *   - errors: every function returns 0 on success or a negative SAGE_E* code, and
+ *     sage_last_error() returns a thread-local human-readable message (the reference raises
+ *     through TORCH_CHECK / std::invalid_argument, csrc/utils.cuh:20-37).
+ * All strides are in ELEMENTS.  Pointers are device pointers unless stated otherwise and must
+ * be 16-byte aligned; row strides must be multiples of 16 elements (the innermost/head_dim
+ * stride is 1, as the reference asserts, core.py:274).  head_dim is 64 or 128 (the Python layer
+ * pads other sizes exactly as core.py:260-271 does).
+ */
+#ifndef SAGE_GFX950_H
+#define SAGE_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGE_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SAGE_API __attribute__((visibility("default")))
+#else
+#define SAGE_API
+#endif
+
+#define SAGE_OK 0
+#define SAGE_EINVAL (-1)      /* bad argument (shape, alignment, unsupported combination) */
+#define SAGE_ELAUNCH (-2)     /* HIP launch / runtime error */
+
+#define SAGE_DTYPE_F16 0
+#define SAGE_DTYPE_BF16 1
+
+/* qk_quant_gran at the op boundary (reference core.py:556-559; 1 is the Triton path's) */
+#define SAGE_GRAN_PER_BLOCK 1
+#define SAGE_GRAN_PER_WARP 2
+#define SAGE_GRAN_PER_THREAD 3
+
+/* rounding / epsilon convention of the INT8 quantiser */
+#define SAGE_QSTYLE_TRITON 0         /* quant_per_block.py:39-47: x/scale, round half away, no eps */
+#define SAGE_QSTYLE_CUDA 1           /* fused.cu:147-186: amax floor 1e-7, x*(127/amax), RNE sat   */
+#define SAGE_QSTYLE_TRITON_THREAD 2  /* quant_per_thread.py:41-44: scale = amax/127 + 1e-7         */
+
+/* PV accumulation */
+#define SAGE_PV_ACCUM_SINGLE 0       /* accumulate every tile straight into the FP32 output          */
+#define SAGE_PV_ACCUM_TWO_LEVEL 1    /* per-64-key tile product from zero, then added to FP32 output */
+
+SAGE_API int sage_abi_version(void);
+SAGE_API const char *sage_last_error(void);
+
+/* Size in bytes of the tiled V^T image for `n_kv_tiles_total` 64-token tiles (all batches, heads). */
+SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total);
+
+/*
+ * INT8 quantisation of Q or K (dense [B,H,L,D] with arbitrary b/h/l strides).
+ * Replaces: quant_per_block_int8_cuda, quant_per_block_int8_fuse_sub_mean_cuda,
+ *           quant_per_warp_int8_cuda            (csrc/fused/fused.h:19-55, pybind.cpp:24-28)
+ *           and the Triton quantisers quant_per_block.py:49-101, quant_per_thread.py:154-203.
+ *  x        fp16/bf16 input
+ *  mean     nullable [B,H,D] K-smoothing mean, same dtype (strides mean_sb, mean_sh)
+ *  out      int8, strides o_sb/o_sh/o_sl
+ *  scale    fp32 [B,H,nscale]; nscale = ceil(L/blk) * slots, slots = 1 (per_block),
+ *           blk/warp (per_warp), blk/warp*8 (per_thread, is_key=0), blk/warp*4 (per_thread, is_key=1)
+ *  blk      rows per block: 128 (Q) or 64 (K);  warp: sub-block rows (32/16 for Q, 64 for K)
+ *  pre_scale multiplied into x before quantising (sm_scale*log2e for the Triton-path Q, else 1)
+ */
+SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, float *scale,
+                       int B, int H, int L, int D,
+                       int64_t x_sb, int64_t x_sh, int64_t x_sl,
+                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                       int64_t mean_sb, int64_t mean_sh,
+                       int blk, int warp, int gran, int is_key, int style,
+                       float pre_scale, int dtype, void *stream);
+
+/*
+ * Same for packed variable-length batches x[sum L, H, D] (per-block only).
+ * Replaces: quant_per_block_varlen.py:60-104.  cu_seqlens [nseq+1] and cu_scale [nseq+1]
+ * (prefix sums of ceil(L_i/blk)) are int32 device arrays; scale is [cu_scale[nseq], H].
+ * `mean` (nullable) is [H, D] shared by all sequences (core.py:432-434 subtracts it in torch).
+ */
+SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *out, float *scale,
+                              const int32_t *cu_seqlens, const int32_t *cu_scale,
+                              int nseq, int max_seqlen, int H, int D,
+                              int64_t x_sl, int64_t x_sh, int64_t o_sl, int64_t o_sh, int64_t mean_sh,
+                              int blk, float pre_scale, int dtype, void *stream);
+
+/*
+ * V pre-pass, FP8: per-channel scale + e4m3 + transpose into the gfx950 PV tile image.
+ * Replaces: transpose_pad_permute_cuda + scale_fuse_quant_cuda (csrc/fused/fused.h:57-75,
+ *           quant.py:224-293).  v is [B,H,L,D] (strides), v_image receives
+ *           sage_v_image_bytes(D, 1, B*H*ceil(L/64)) bytes, v_scale [B,H,D] fp32,
+ *           amax_ws [B,H,D] fp32 scratch (zeroed by the call).  scale_max = 448 (e4m3 max).
+ */
+SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *amax_ws,
+                    int B, int H, int L, int D,
+                    int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                    float scale_max, int dtype, void *stream);
+
+/* V pre-pass, FP16: (bf16 -> fp16) + transpose into the tile image.  Replaces `v.to(float16)`
+ * (core.py:297-298,613).  Dense. */
+SAGE_API int sage_prep_v_f16(const void *v, void *v_image, int B, int H, int L, int D,
+                    int64_t v_sb, int64_t v_sh, int64_t v_sl, int dtype, void *stream);
+
+/* Same for packed v[sum L, H, D]; cu_tiles = prefix sums of ceil(L_i/64); the image holds
+ * cu_tiles[nseq]*H tiles ordered [tile, head]. */
+SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t *cu_seqlens,
+                           const int32_t *cu_tiles, int nseq, int max_seqlen, int H, int D,
+                           int64_t v_sl, int64_t v_sh, int dtype, void *stream);
+
+/*
+ * Fused attention, INT8 QK^T + FP8 PV.
+ * Replaces: qk_int8_sv_f8_accum_f32_fuse_v_scale_attn[_inst_buf],
+ *           qk_int8_sv_f8_accum_f16_fuse_v_scale_attn_inst_buf,
+ *           qk_int8_sv_f8_accum_f32_fuse_v_scale_fuse_v_mean_attn
+ *           (csrc/qattn/attn_cuda_sm89.h:19-104, pybind_sm89.cpp:21-30) and the sm90 ops
+ *           (attn_cuda_sm90.h:19-43).
+ *  q,k       int8 with strides; q_scale/k_scale as produced by sage_quant_qk_int8 with the same
+ *            `qk_quant_gran` (and q_warp = 32 or 16 for per_warp)
+ *  v_image   from sage_prep_v_fp8; v_scale [B,Hkv,D]; v_mean nullable [B,Hkv,D]
+ *  o         fp16/bf16 (out_dtype) with strides; lse nullable fp32 [B,Hq,Lq] (log2 units + max,
+ *            i.e. what the reference kernels return before core.py:823-826 rescales it)
+ *  sm_scale_log2  factor applied to dequantised scores: sm_scale*log2e, or 1.0 when it was
+ *            folded into Q at quantisation time
+ */
+SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                            const float *q_scale, const float *k_scale,
+                            const float *v_scale, const float *v_mean,
+                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                            int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                            int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                            int is_causal, int qk_quant_gran, int q_warp,
+                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream);
+
+/* Fused attention, INT8 QK^T + FP16 PV (FP32 accumulate).
+ * Replaces: qk_int8_sv_f16_accum_f32_attn, _accum_f16_attn, _accum_f16_attn_inst_buf,
+ *           _accum_f16_fuse_v_mean_attn (csrc/qattn/attn_cuda_sm80.h:19-65) and the Triton
+ *           `forward` ops attn_qk_int8_per_block.py:130, _causal.py:124. */
+SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                             const float *q_scale, const float *k_scale, const float *v_mean,
+                             int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                             int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                             int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                             int is_causal, int qk_quant_gran, int q_warp,
+                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream);
+
+/* Variable-length fused attention (per-block scales, FP16 PV), packed q/o [sum Lq, Hq, D],
+ * k [sum Lk, Hkv, D].  Replaces: attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125.
+ * cu_q_scale / cu_k_scale: prefix sums of ceil(Lq_i/128) / ceil(Lk_i/64) (also the V tile prefix). */
+SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
+                                    const float *q_scale, const float *k_scale,
+                                    const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale,
+                                    int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                    int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh,
+                                    int64_t o_sl, int64_t o_sh,
+                                    int is_causal, float sm_scale_log2, int pv_accum, int out_dtype,
+                                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_GFX950_H */

@@ -189,10 +189,13 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
         km = None
     vh = v if dtype == F16 else convert(to_f32(v, dtype), "f16")   # core.py:297-298,613
     if pv == "f16_triton" or qk_quant_gran == "per_block":
+        # Triton API: "triton" rounding (quant_per_block.py); per_block under the CUDA-named APIs
+        # (a gfx950 extension) uses the CUDA quantiser's rounding (quant.py:22-103 -> fused.cu:64-198)
+        style = STYLE_TRITON if pv == "f16_triton" else STYLE_CUDA
         gq, nq = group_index(Lq, "per_block", "q", 128, 128)
         gk, nk = group_index(Lk, "per_block", "k", 64, 64)
-        q8, qs = quant_int8(q, dtype, gq, nq, pre_scale=np.float32(sm_scale * LOG2E), style=STYLE_TRITON)
-        k8, ks = quant_int8(k, dtype, gk, nk, style=STYLE_TRITON, mean=km)
+        q8, qs = quant_int8(q, dtype, gq, nq, pre_scale=np.float32(sm_scale * LOG2E), style=style)
+        k8, ks = quant_int8(k, dtype, gk, nk, style=style, mean=km)
         c = 1.0
     elif qk_quant_gran == "per_warp":
         gq, nq = group_index(Lq, "per_warp", "q", 128, 32)

@@ -1,0 +1,86 @@
+"""ctypes binding of libsage_gfx950.so (include/sage_gfx950.h).
+
+The library is the product: if it cannot be loaded this module raises -- there is no eager /
+PyTorch / CPU fallback anywhere in ``sageattention_amd``.  Build it with
+``python __graft_entry__.py`` (or ``make -C sageattention_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsage_gfx950.so")
+
+# mirrors of the header's constants
+ABI_VERSION = 1
+DTYPE_F16, DTYPE_BF16 = 0, 1
+GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
+QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
+PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL = 0, 1
+
+# every symbol include/sage_gfx950.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+SYMBOLS = {
+    "sage_abi_version": (c_int, []),
+    "sage_last_error": (ctypes.c_char_p, []),
+    "sage_v_image_bytes": (c_int64, [_I, _I, _L]),
+    "sage_quant_qk_int8": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
+                                   _I, _I, _I, _I, _I, _F, _I, _P]),
+    "sage_quant_qk_int8_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L,
+                                          _I, _F, _I, _P]),
+    "sage_prep_v_fp8": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
+    "sage_prep_v_f16": (c_int, [_P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "sage_prep_v_f16_varlen": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
+    "sage_attn_qk_int8_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+    "sage_attn_qk_int8_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+    "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+                                                _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+}
+
+
+class SageLibraryError(RuntimeError):
+    """libsage_gfx950.so is missing or does not match include/sage_gfx950.h."""
+
+
+class SageKernelError(RuntimeError):
+    """A C-ABI call returned a negative status (SAGE_EINVAL / SAGE_ELAUNCH)."""
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library (once); raise loudly if it is absent -- no fallback path exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SageLibraryError(
+            f"{LIB_PATH} not found: the gfx950 HIP extension has not been built. "
+            "Run `python __graft_entry__.py` (or `make -C sageattention_amd/csrc`). "
+            "sageattention_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SageLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.sage_abi_version()
+    if got != ABI_VERSION:
+        raise SageLibraryError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sage_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")          # the reference raises ValueError for bad arguments
+        raise SageKernelError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,257 @@
+"""Public API of sageattention_amd -- the drop-in for ``sageattention/core.py`` on MI355X.
+
+Same six public names, same signatures, same kwargs and error behaviour as the reference
+(``/root/reference/sageattention/core.py``: ``sageattn`` :79, ``sageattn_qk_int8_pv_fp16_triton``
+:160, ``sageattn_varlen`` :334, ``sageattn_qk_int8_pv_fp16_cuda`` :451,
+``sageattn_qk_int8_pv_fp8_cuda`` :636, ``sageattn_qk_int8_pv_fp8_cuda_sm90`` :829), so
+``F.scaled_dot_product_attention = sageattn`` in the CogVideoX / Hunyuan / Wan examples keeps
+working.  Host code here is plumbing only (padding, K mean, allocation, LSE fix-up -- exactly
+what the reference does in Python); every tensor-sized computation except ``k.mean`` runs in
+the hand-written HIP kernels behind ``libsage_gfx950.so``.  There is no fallback path: CPU
+tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Any, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _cabi
+from .quant import (LOG2E, _dims, _p, _stream, per_block_int8, per_block_int8_varlen, per_channel_fp8,
+                    per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen)
+
+_SUPPORTED_ARCH_PREFIX = "gfx950"
+
+
+def get_gcn_arch(device: torch.device) -> str:
+    """ROCm analogue of the reference's ``get_cuda_arch_versions`` (core.py:71-76)."""
+    return torch.cuda.get_device_properties(device).gcnArchName.split(":")[0]
+
+
+def _check_inputs(q, k, v):
+    dtype = q.dtype
+    assert q.is_cuda, "Input tensors must be on cuda."
+    assert dtype in [torch.float16, torch.bfloat16], "Input tensors must be in dtype of torch.float16 or torch.bfloat16"
+    assert q.device == k.device == v.device, "All tensors must be on the same device."
+    assert q.dtype == k.dtype == v.dtype, "All tensors must have the same dtype."
+
+
+def _pad_head_dim(q, k, v):
+    """core.py:260-271: zero-pad head_dim to 64 / 128; > 128 is rejected."""
+    head_dim_og = q.size(-1)
+    if head_dim_og < 64:
+        q, k, v = (F.pad(t, (0, 64 - head_dim_og)) for t in (q, k, v))
+    elif 64 < head_dim_og < 128:
+        q, k, v = (F.pad(t, (0, 128 - head_dim_og)) for t in (q, k, v))
+    elif head_dim_og > 128:
+        raise ValueError(f"Unsupported head_dim: {head_dim_og}")
+    return q, k, v, head_dim_og
+
+
+def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
+    """core.py:279-295: km = mean of k over the sequence, and q.km^T for the LSE fix-up."""
+    seq_dim = 1 if tensor_layout == "NHD" else 2
+    nh_dim = 2 if tensor_layout == "NHD" else 1
+    if not smooth_k:
+        return None, None
+    km = k.mean(dim=seq_dim, keepdim=True)
+    lse_correction = None
+    if return_lse:
+        g = q.size(nh_dim) // k.size(nh_dim)
+        km_b = torch.repeat_interleave(km, g, dim=nh_dim) if g > 1 else km
+        if tensor_layout == "NHD":
+            lse_correction = torch.matmul(q.transpose(1, 2), km_b.transpose(1, 2).transpose(2, 3)).squeeze(-1).to(torch.float32)
+        else:
+            lse_correction = torch.matmul(q, km_b.transpose(2, 3)).squeeze(-1).to(torch.float32)
+    return km, lse_correction
+
+
+def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dtype, tensor_layout, is_causal,
+                gran, q_warp, sm_scale_log2, two_level, return_lse):
+    """Allocate ``o`` (+ ``lse``) and launch the fused kernel through the C ABI."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q_int8, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
+    assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
+    o = torch.empty(q_int8.shape, dtype=out_dtype, device=q_int8.device)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=o.device) if return_lse else None
+    code = _cabi.DTYPE_F16 if out_dtype == torch.float16 else _cabi.DTYPE_BF16
+    accum = _cabi.PV_ACCUM_TWO_LEVEL if two_level else _cabi.PV_ACCUM_SINGLE
+    lib = _cabi.load()
+    if fp8:
+        rc = lib.sage_attn_qk_int8_pv_f8(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
+                                         _p(v_scale), None, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                                         o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
+                                         _stream(o))
+        _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
+    else:
+        rc = lib.sage_attn_qk_int8_pv_f16(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
+                                          None, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                                          o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
+                                          _stream(o))
+        _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
+    return o, lse
+
+
+def _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale):
+    o = o[..., :head_dim_og]
+    if return_lse:   # core.py:328-329: kernel LSE is in log2 units
+        return o, lse / 1.44269504 + lse_correction * sm_scale if smooth_k else lse / 1.44269504
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: str = "HND", is_causal: bool = False,
+             sm_scale: Optional[float] = None, return_lse: bool = False, **kwargs: Any):
+    """Select the implementation for the device, as the reference does per compute capability
+    (core.py:143-157).  On gfx950 that is INT8 QK^T + FP8 PV with two-level FP32 accumulation
+    (the reference's sm90 choice, ``pv_accum_dtype="fp32+fp32"``).  Extra SDPA-style kwargs
+    (``attn_mask=``, ``dropout_p=``, ``scale=`` ...) are accepted and ignored exactly as the
+    reference ignores them."""
+    arch = get_gcn_arch(q.device) if q.is_cuda else "cpu"
+    if arch.startswith(_SUPPORTED_ARCH_PREFIX):
+        return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                                            return_lse=return_lse, pv_accum_dtype="fp32+fp32")
+    raise ValueError(f"Unsupported architecture: {arch} (sageattention_amd targets gfx950 / MI355X only)")
+
+
+def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantization_backend: str = "triton",
+                                    is_causal: bool = False, attn_mask: Optional[torch.Tensor] = None,
+                                    sm_scale: Optional[float] = None, smooth_k: bool = True, return_lse: bool = False,
+                                    **kwargs: Any):
+    """Per-block INT8 Q/K (sm_scale*log2e folded into Q), FP16 PV, per-tile product added to an
+    FP32 buffer (reference core.py:160-331; the name is kept for drop-in -- there is no Triton
+    here, the same HIP kernel family runs it)."""
+    dtype = q.dtype
+    _check_inputs(q, k, v)
+    if attn_mask is not None:
+        raise NotImplementedError("attn_mask is not supported by the gfx950 kernels yet")
+    if quantization_backend not in ("triton", "cuda"):
+        raise ValueError(f"Unsupported quantization backend: {quantization_backend}")
+    torch.cuda.set_device(v.device)
+    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    if sm_scale is None:
+        sm_scale = 1.0 / (head_dim_og ** 0.5)
+    if is_causal:
+        assert q.size(1 if tensor_layout == "NHD" else 2) == k.size(1 if tensor_layout == "NHD" else 2), \
+            "qo_len and kv_len must be equal for causal attention"
+    q_int8, q_scale, k_int8, k_scale = per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
+                                                      quantization_backend=quantization_backend)
+    v_image = prep_v_fp16(v, tensor_layout)
+    o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
+                         _cabi.GRAN_PER_BLOCK, 128, 1.0, True, return_lse)
+    return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
+
+
+def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, is_causal: bool = False,
+                    sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any) -> torch.Tensor:
+    """Variable-length batches, q/k/v packed as ``[sum L, H, D]`` (reference core.py:334-448)."""
+    dtype = q.dtype
+    _check_inputs(q, k, v)
+    torch.cuda.set_device(v.device)
+    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    assert cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous(), "cu_seqlens_q and cu_seqlens_k must be contiguous."
+    Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[2]
+    assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
+    km = k.mean(dim=0, keepdim=True) if smooth_k else None   # over ALL packed tokens, as core.py:432-434
+    if sm_scale is None:
+        sm_scale = 1.0 / (head_dim_og ** 0.5)
+    q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
+        q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale)
+    cu_q = cu_seqlens_q.to(torch.int32).contiguous()
+    cu_k = cu_seqlens_k.to(torch.int32).contiguous()
+    v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k)
+    o = torch.empty(q.shape, dtype=dtype, device=q.device)
+    code = _cabi.DTYPE_F16 if dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
+        _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(q_scale), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_qs), _p(cu_ks),
+        cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),
+        o.stride(0), o.stride(1), int(is_causal), 1.0, _cabi.PV_ACCUM_TWO_LEVEL, code, _stream(o))
+    _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
+    return o[..., :head_dim_og]
+
+
+def _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale):
+    """Returns (q_int8, q_scale, k_int8, k_scale, gran code, q_warp, sm_scale_log2)."""
+    if qk_quant_gran == "per_warp":
+        return (*per_warp_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=64),
+                _cabi.GRAN_PER_WARP, warpq, sm_scale * LOG2E)
+    if qk_quant_gran == "per_thread":
+        return (*per_thread_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64),
+                _cabi.GRAN_PER_THREAD, 32, sm_scale * LOG2E)
+    # "per_block": gfx950 extension (the Triton path's granularity with the CUDA rounding)
+    return (*per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout, quantization_backend="cuda"),
+            _cabi.GRAN_PER_BLOCK, 128, 1.0)
+
+
+def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                                  qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
+                                  pv_accum_dtype: str = "fp32", smooth_k: bool = True, smooth_v: bool = False,
+                                  return_lse: bool = False, **kwargs: Any):
+    """INT8 QK^T + FP16 PV (reference core.py:451-633).  ``pv_accum_dtype`` "fp32" accumulates
+    straight into FP32; "fp16+fp32" keeps the reference's per-tile buffer structure (the tile
+    buffer is FP32 here: CDNA4 MFMA has no FP16 accumulator); "fp16" maps to "fp32"."""
+    dtype = q.dtype
+    _check_inputs(q, k, v)
+    assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp16", "fp16+fp32"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    torch.cuda.set_device(v.device)
+    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    if sm_scale is None:
+        sm_scale = head_dim_og ** -0.5
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    if smooth_v:
+        warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")   # FP32 accumulators on gfx950
+    warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32" and qk_quant_gran == "per_warp") else 32
+    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale)
+    v_image = prep_v_fp16(v, tensor_layout)
+    o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
+                         gran, q_warp, sm_log2, pv_accum_dtype == "fp16+fp32", return_lse)
+    return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
+
+
+def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                                 qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
+                                 pv_accum_dtype: str = "fp32+fp16", smooth_k: bool = True, smooth_v: bool = False,
+                                 return_lse: bool = False, **kwargs: Any):
+    """INT8 QK^T + FP8 (e4m3) PV (reference core.py:636-826).  "fp32+fp32" and "fp32+fp16" both
+    run the two-level kernel with an FP32 tile buffer (gfx950's FP8 MFMA only writes FP32, so V
+    keeps the full ``scale_max=448``; the reference's 2.25 is an FP16-accumulator artefact,
+    core.py:805-807); "fp32" accumulates every tile straight into the output registers."""
+    dtype = q.dtype
+    _check_inputs(q, k, v)
+    assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    if pv_accum_dtype not in ("fp32", "fp32+fp32", "fp32+fp16"):
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    torch.cuda.set_device(v.device)
+    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    if sm_scale is None:
+        sm_scale = head_dim_og ** -0.5
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    if smooth_v:
+        warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")
+    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)
+    v_image, v_scale, _ = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=False)
+    o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
+                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse)
+    return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
+
+
+def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
+                                      qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
+                                      pv_accum_dtype: str = "fp32+fp32", smooth_k: bool = True, return_lse: bool = False,
+                                      **kwargs: Any):
+    """Kept for drop-in (reference core.py:829-996): same gfx950 kernel, two-level accumulation."""
+    if pv_accum_dtype == "fp32":
+        raise NotImplementedError("Please use pv_accum_dtype='fp32+fp32' for sm90.")   # core.py:985-986
+    return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, qk_quant_gran=qk_quant_gran,
+                                        sm_scale=sm_scale, pv_accum_dtype=pv_accum_dtype, smooth_k=smooth_k,
+                                        return_lse=return_lse)

@@ -1,0 +1,245 @@
+// sage_cabi.hip -- extern "C" entry points declared in include/sage_gfx950.h.
+// Validates arguments, fills the kernel parameter blocks, launches on the caller's stream.
+#include "../../include/sage_gfx950.h"
+#include "sage_common.h"
+#include "sage_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_launch(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) return fail(SAGE_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SAGE_OK;
+}
+
+#define SAGE_REQUIRE(cond, ...) do { if (!(cond)) return fail(SAGE_EINVAL, __VA_ARGS__); } while (0)
+
+int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
+                const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_qs, const int32_t *cu_ks,
+                int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
+    SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d)", B, Hq, Hkv, Lq);
+    SAGE_REQUIRE(varlen || Lk > 0, "kv_len must be positive");
+    SAGE_REQUIRE(Hq % Hkv == 0, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+    SAGE_REQUIRE(out_dtype == SAGE_DTYPE_F16 || out_dtype == SAGE_DTYPE_BF16, "bad out_dtype %d", out_dtype);
+    SAGE_REQUIRE(gran >= SAGE_GRAN_PER_BLOCK && gran <= SAGE_GRAN_PER_THREAD, "bad qk_quant_gran %d", gran);
+    SAGE_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v_image) && aligned16(o), "q/k/v/o must be 16-byte aligned");
+    SAGE_REQUIRE(q_sl % 16 == 0 && k_sl % 16 == 0 && q_sh % 16 == 0 && k_sh % 16 == 0 && q_sb % 16 == 0 && k_sb % 16 == 0,
+                 "int8 q/k strides must be multiples of 16");
+    SAGE_REQUIRE(o_sl % 8 == 0 && o_sh % 8 == 0 && o_sb % 8 == 0, "output strides must be multiples of 8 elements");
+    SAGE_REQUIRE(!fp8 || v_scale, "fp8 PV needs v_scale");
+    SAGE_REQUIRE(!varlen || (cu_q && cu_k && cu_qs && cu_ks), "varlen needs cu_seqlens arrays");
+
+    sage::AttnParams p{};
+    p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
+    p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
+    p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+    p.Lq = Lq; p.Lk = Lk;
+    p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
+    p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+    p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl;
+    bool kthread = false;
+    if (gran == SAGE_GRAN_PER_BLOCK) { p.q_gran = sage::QG_PER_BLOCK; p.qs_per_blk = 1; }
+    else if (gran == SAGE_GRAN_PER_WARP) {
+        SAGE_REQUIRE(q_warp == 32 || q_warp == 16, "per_warp q_warp must be 32 or 16 (got %d)", q_warp);
+        p.q_gran = q_warp == 32 ? sage::QG_PER_WARP32 : sage::QG_PER_WARP16;
+        p.qs_per_blk = sage::BLKQ / q_warp;
+    } else {
+        SAGE_REQUIRE(q_warp == 32, "per_thread is defined for WARPQ=32 only (got %d)", q_warp);
+        p.q_gran = sage::QG_PER_THREAD; p.qs_per_blk = 32; kthread = true;
+    }
+    SAGE_REQUIRE(!varlen || gran == SAGE_GRAN_PER_BLOCK, "varlen supports per_block scales only");
+    p.nqs = p.nqblk * p.qs_per_blk;
+    p.nks = ((Lk + sage::BLKK - 1) / sage::BLKK) * (kthread ? 4 : 1);
+    p.out_dtype = out_dtype;
+    p.lse_sh = 0;
+    p.sm_scale_log2 = sm_scale_log2;
+    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, pv_accum == SAGE_PV_ACCUM_TWO_LEVEL,
+                                          static_cast<hipStream_t>(stream)), "sage_attn launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+SAGE_API int sage_abi_version(void) { return SAGE_ABI_VERSION; }
+SAGE_API const char *sage_last_error(void) { return g_err; }
+
+SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total)
+{
+    return n_kv_tiles_total * (int64_t)head_dim * (fp8 ? 64 : 128);
+}
+
+SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, float *scale,
+                       int B, int H, int L, int D,
+                       int64_t x_sb, int64_t x_sh, int64_t x_sl,
+                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                       int64_t mean_sb, int64_t mean_sh,
+                       int blk, int warp, int gran, int is_key, int style,
+                       float pre_scale, int dtype, void *stream)
+{
+    SAGE_REQUIRE(x && out && scale, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(blk == 64 || blk == 128, "blk must be 64 or 128 (got %d)", blk);
+    SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(style >= 0 && style <= 2, "bad style %d", style);
+    SAGE_REQUIRE(aligned16(x) && aligned16(out) && (!mean || aligned16(mean)), "x/out/mean must be 16-byte aligned");
+    SAGE_REQUIRE(x_sl % 8 == 0 && x_sh % 8 == 0 && x_sb % 8 == 0, "input strides must be multiples of 8 elements");
+    SAGE_REQUIRE(o_sl % 16 == 0 && o_sh % 16 == 0 && o_sb % 16 == 0, "int8 output strides must be multiples of 16");
+    SAGE_REQUIRE(!mean || (mean_sb % 8 == 0 && mean_sh % 8 == 0), "mean strides must be multiples of 8 elements");
+    sage::QuantParams p{};
+    p.x = x; p.mean = mean; p.out = out; p.scale = scale; p.cu = nullptr; p.cu_scale = nullptr;
+    p.B = B; p.H = H; p.L = L; p.D = D;
+    p.x_sb = x_sb; p.x_sh = x_sh; p.x_sl = x_sl; p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl;
+    p.mean_sb = mean_sb; p.mean_sh = mean_sh;
+    p.blk = blk; p.warp = warp; p.style = style; p.dtype = dtype; p.pre_scale = pre_scale;
+    int slots = 1;
+    if (gran == SAGE_GRAN_PER_BLOCK) { p.gran = sage::GR_BLOCK; p.warp = blk; }
+    else if (gran == SAGE_GRAN_PER_WARP) {
+        SAGE_REQUIRE(warp > 0 && blk % warp == 0 && blk / warp <= 32, "bad warp block %d for blk %d", warp, blk);
+        p.gran = sage::GR_WARP; slots = blk / warp;
+    } else if (gran == SAGE_GRAN_PER_THREAD) {
+        SAGE_REQUIRE(warp > 0 && blk % warp == 0 && warp % 8 == 0, "bad warp block %d for blk %d", warp, blk);
+        p.gran = is_key ? sage::GR_THREAD_K : sage::GR_THREAD_Q;
+        slots = (blk / warp) * (is_key ? 4 : 8);
+        SAGE_REQUIRE(slots <= 32, "too many scale groups per block (%d)", slots);
+    } else return fail(SAGE_EINVAL, "bad qk_quant_gran %d", gran);
+    p.nscale = ((L + blk - 1) / blk) * slots;
+    return check_launch(sage::launch_quant_int8(p, static_cast<hipStream_t>(stream)), "sage_quant_qk_int8 launch");
+}
+
+SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *out, float *scale,
+                              const int32_t *cu_seqlens, const int32_t *cu_scale,
+                              int nseq, int max_seqlen, int H, int D,
+                              int64_t x_sl, int64_t x_sh, int64_t o_sl, int64_t o_sh, int64_t mean_sh,
+                              int blk, float pre_scale, int dtype, void *stream)
+{
+    SAGE_REQUIRE(x && out && scale && cu_seqlens && cu_scale, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(blk == 64 || blk == 128, "blk must be 64 or 128 (got %d)", blk);
+    SAGE_REQUIRE(nseq > 0 && H > 0 && max_seqlen > 0, "empty batch");
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(aligned16(x) && aligned16(out) && (!mean || aligned16(mean)), "x/out/mean must be 16-byte aligned");
+    SAGE_REQUIRE(x_sl % 8 == 0 && x_sh % 8 == 0 && o_sl % 16 == 0 && o_sh % 16 == 0, "bad strides");
+    sage::QuantParams p{};
+    p.x = x; p.mean = mean; p.out = out; p.scale = scale; p.cu = cu_seqlens; p.cu_scale = cu_scale;
+    p.B = nseq; p.H = H; p.L = max_seqlen; p.D = D;
+    p.x_sb = 0; p.x_sh = x_sh; p.x_sl = x_sl; p.o_sb = 0; p.o_sh = o_sh; p.o_sl = o_sl;
+    p.mean_sb = 0; p.mean_sh = mean_sh;
+    p.blk = blk; p.warp = blk; p.gran = sage::GR_BLOCK; p.style = sage::QS_TRITON; p.dtype = dtype;
+    p.pre_scale = pre_scale; p.nscale = 0;
+    return check_launch(sage::launch_quant_int8(p, static_cast<hipStream_t>(stream)), "sage_quant_qk_int8_varlen launch");
+}
+
+static int prep_v_common(const void *v, void *v_image, float *v_scale, float *amax_ws, const int32_t *cu,
+                         const int32_t *cu_tiles, int B, int H, int L, int D,
+                         int64_t v_sb, int64_t v_sh, int64_t v_sl, float scale_max, int dtype, int fp8, void *stream)
+{
+    SAGE_REQUIRE(v && v_image, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
+    SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "v strides must be multiples of 8 elements");
+    sage::PrepVParams p{};
+    p.v = v; p.out = v_image; p.amax = amax_ws; p.v_scale = v_scale; p.cu = cu; p.cu_tiles = cu_tiles;
+    p.B = B; p.H = H; p.L = L; p.D = D; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+    p.dtype = dtype; p.fp8 = fp8; p.scale_max = scale_max;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (fp8) {
+        SAGE_REQUIRE(v_scale && amax_ws, "fp8 V pre-pass needs v_scale and amax workspace");
+        SAGE_REQUIRE(scale_max > 0.0f, "scale_max must be positive");
+        hipError_t e = hipMemsetAsync(amax_ws, 0, sizeof(float) * (size_t)B * H * D, s);
+        if (e != hipSuccess) return check_launch(e, "amax workspace memset");
+        int rc = check_launch(sage::launch_v_absmax(p, s), "sage_v_absmax launch");
+        if (rc != SAGE_OK) return rc;
+    }
+    return check_launch(sage::launch_prep_v(p, s), "sage_prep_v launch");
+}
+
+SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *amax_ws,
+                    int B, int H, int L, int D, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                    float scale_max, int dtype, void *stream)
+{
+    return prep_v_common(v, v_image, v_scale, amax_ws, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl, scale_max, dtype, 1, stream);
+}
+
+SAGE_API int sage_prep_v_f16(const void *v, void *v_image, int B, int H, int L, int D,
+                    int64_t v_sb, int64_t v_sh, int64_t v_sl, int dtype, void *stream)
+{
+    return prep_v_common(v, v_image, nullptr, nullptr, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl, 0.0f, dtype, 0, stream);
+}
+
+SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t *cu_seqlens, const int32_t *cu_tiles,
+                           int nseq, int max_seqlen, int H, int D, int64_t v_sl, int64_t v_sh, int dtype, void *stream)
+{
+    SAGE_REQUIRE(cu_seqlens && cu_tiles, "varlen needs cu_seqlens and cu_tiles");
+    return prep_v_common(v, v_image, nullptr, nullptr, cu_seqlens, cu_tiles, nseq, H, max_seqlen, D, 0, v_sh, v_sl, 0.0f, dtype, 0, stream);
+}
+
+SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                            const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
+                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                            int is_causal, int qk_quant_gran, int q_warp,
+                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+{
+    return attn_common(true, false, q, k, v_image, o, lse, q_scale, k_scale, v_scale, v_mean, nullptr, nullptr, nullptr, nullptr,
+                       B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream);
+}
+
+SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                             const float *q_scale, const float *k_scale, const float *v_mean,
+                             int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                             int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                             int is_causal, int qk_quant_gran, int q_warp,
+                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+{
+    return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, v_mean, nullptr, nullptr, nullptr, nullptr,
+                       B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream);
+}
+
+SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
+                                    const float *q_scale, const float *k_scale,
+                                    const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale,
+                                    int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                    int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
+                                    int is_causal, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+{
+    return attn_common(false, true, q, k, v_image, o, nullptr, q_scale, k_scale, nullptr, nullptr,
+                       cu_seqlens_q, cu_seqlens_k, cu_q_scale, cu_k_scale,
+                       nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
+                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream);
+}
+
+}  // extern "C"

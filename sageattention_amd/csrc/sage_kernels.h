@@ -1,0 +1,82 @@
+// sage_kernels.h -- internal launch interface between the C ABI (sage_cabi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sage {
+
+// query-scale granularity as seen by the attention kernel (slots per 128-row block)
+enum : int { QG_PER_BLOCK = 1, QG_PER_WARP32 = 2, QG_PER_THREAD = 3, QG_PER_WARP16 = 4 };
+
+struct AttnParams {
+    const int8_t *q;          // int8, strides below (elements)
+    const int8_t *k;
+    const void *v;            // gfx950 tiled V^T image (see sage_prep_v.hip)
+    void *o;                  // fp16 / bf16
+    float *lse;               // nullable, [B,Hq,Lq] log2 units
+    const float *q_scale;
+    const float *k_scale;
+    const float *v_scale;     // [B,Hkv,D] (fp8 PV) or null
+    const float *v_mean;      // [B,Hkv,D] or null
+    const int32_t *cu_q;      // varlen only (null => dense)
+    const int32_t *cu_k;
+    const int32_t *cu_qs;     // prefix sums of ceil(Lq_i/128)
+    const int32_t *cu_ks;     // prefix sums of ceil(Lk_i/64)
+    int B, Hq, Hkv, group;    // group = Hq / Hkv
+    int Lq, Lk;               // dense lengths; varlen: max lengths (grid sizing only)
+    int nqblk;                // ceil(max Lq / 128)
+    long q_sb, q_sh, q_sl;
+    long k_sb, k_sh, k_sl;
+    long o_sb, o_sh, o_sl;
+    int nqs, nks;             // scale slots per (b,h) for q / k (dense)
+    int qs_per_blk;           // q scale slots per 128-row block
+    int q_gran;               // QG_*
+    int out_dtype;            // DT_F16 / DT_BF16
+    long lse_sh;              // varlen lse head stride (unused for dense)
+    float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain
+};
+
+hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
+                       bool two_level, hipStream_t stream);
+
+// ---- INT8 quantisation of Q / K ----------------------------------------------------------------
+enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style
+enum : int { GR_BLOCK = 1, GR_WARP = 2, GR_THREAD_Q = 3, GR_THREAD_K = 5 };  // row -> scale group map
+
+struct QuantParams {
+    const void *x;            // fp16 / bf16
+    const void *mean;         // nullable [B,H,D] (strides mean_sb, mean_sh)
+    int8_t *out;
+    float *scale;
+    const int32_t *cu;        // varlen: cu_seqlens (null => dense)
+    const int32_t *cu_scale;  // varlen: prefix of blocks
+    int B, H, L, D;
+    long x_sb, x_sh, x_sl;
+    long o_sb, o_sh, o_sl;
+    long mean_sb, mean_sh;
+    int nscale;               // dense: scale slots per (b,h)
+    int blk;                  // rows per workgroup: 128 (Q) / 64 (K)
+    int warp;                 // sub-group rows for GR_WARP / GR_THREAD_* (32, 16, 64)
+    int gran, style, dtype;
+    float pre_scale;
+};
+hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream);
+
+// ---- V pre-pass -------------------------------------------------------------------------------
+struct PrepVParams {
+    const void *v;            // fp16 / bf16 [.., L, D] with strides
+    void *out;                // tiled V^T image, fp8 or fp16
+    float *amax;              // [B,H,D] workspace (fp8): per-channel abs max (as float)
+    float *v_scale;           // [B,H,D] out (fp8)
+    const int32_t *cu;        // varlen
+    const int32_t *cu_tiles;  // varlen: prefix of ceil(L_i/64)
+    int B, H, L, D;
+    long v_sb, v_sh, v_sl;
+    int dtype;
+    int fp8;                  // 1: e4m3 output, 0: fp16 output
+    float scale_max;
+};
+hipError_t launch_v_absmax(const PrepVParams &p, hipStream_t stream);
+hipError_t launch_prep_v(const PrepVParams &p, hipStream_t stream);
+
+}  // namespace sage

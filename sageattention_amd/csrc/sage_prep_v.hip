@@ -1,0 +1,175 @@
+// sage_prep_v.hip -- V pre-pass: per-channel FP8 quantisation (or fp16 pass-through) fused with
+// the transpose into the gfx950 PV-operand tile image.
+//
+// Replaces the reference's three-kernel V path
+//   csrc/fused/fused.cu:262-313  TransposePadPermuteKernel ([L,D] -> [D, ceil64(L)], NVIDIA order)
+//   csrc/fused/fused.cu:316-427  MeanScaleKernel           (per-(b,h,d) amax, scale, e4m3 cast)
+//   sageattention/quant.py:224-293 per_channel_fp8          (host wrapper)
+// and, for the FP16-PV paths, `v.to(torch.float16)` (core.py:297-298,613).
+//
+// Tile image (one per 64 tokens of one (batch, kv-head)), D rows:
+//   fp8 : row d = 64 bytes, byte (16*ch' + i) holds token tau(16*ch + i), ch' = ch ^ ((d>>2)&3)
+//   fp16: row d = 128 bytes, elem (8*ch' + i) holds token tau( 8*ch + i), ch' = ch ^ ((d>>1)&7)
+// with tau() = sage::pv_token_of_position.  The image is byte-for-byte what the attention
+// kernel keeps in LDS, so the tile load is a linear 16-B-per-lane copy and the PV A-operand
+// reads are conflict-free ds_read_b128.  Tokens >= L are zero (the reference zero-pads too,
+// fused.cu:283-286) so masked probabilities never multiply garbage.
+//
+// HBM traffic: absmax pass reads V once (2 B/elt); the quantise pass reads it again and writes
+// 1 B/elt (fp8) -- 5 B/elt against the reference's 9 B/elt (fp16 intermediate written + read twice).
+#include "sage_common.h"
+#include "sage_kernels.h"
+
+namespace sage {
+
+constexpr int kSlab = 256;   // tokens per absmax workgroup
+
+template <int D, int DT>
+__global__ void __launch_bounds__(256)
+v_absmax_kernel(const PrepVParams p)
+{
+    __shared__ unsigned cmax[D];
+    constexpr int TPR = D / 8;           // threads per row (16 B each)
+    constexpr int RPI = 256 / TPR;       // rows per iteration
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (tid < D) cmax[tid] = 0u;
+    __syncthreads();
+    const uint16_t *v = reinterpret_cast<const uint16_t *>(p.v) + (long)b * p.v_sb + (long)h * p.v_sh;
+    const int c8 = (tid % TPR) * 8;
+    float mx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) mx[j] = 0.0f;
+    const int end = min(p.L, slab * kSlab + kSlab);
+    for (int r = slab * kSlab + tid / TPR; r < end; r += RPI) {
+        const v4u raw = *reinterpret_cast<const v4u *>(v + (long)r * p.v_sl + c8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned w = raw[j >> 1];
+            mx[j] = fmaxf(mx[j], fabsf(ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)))));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) atomicMax(&cmax[c8 + j], __float_as_uint(mx[j]));
+    __syncthreads();
+    if (tid < D)
+        atomicMax(reinterpret_cast<unsigned *>(p.amax) + ((long)b * p.H + h) * D + tid, cmax[tid]);
+}
+
+template <int D, int DT, bool FP8>
+__global__ void __launch_bounds__(256)
+prep_v_kernel(const PrepVParams p)
+{
+    constexpr int LDT = D + 8;                                  // padded row (16-B aligned)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[BLKK * LDT];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int L = p.L;
+    long voff, tile_idx;
+    if (p.cu != nullptr) {
+        const int s0 = p.cu[b];
+        L = p.cu[b + 1] - s0;
+        if (t * BLKK >= L) return;
+        voff = (long)s0 * p.v_sl + (long)h * p.v_sh;
+        tile_idx = ((long)p.cu_tiles[b] + t) * p.H + h;
+    } else {
+        voff = (long)b * p.v_sb + (long)h * p.v_sh;
+        tile_idx = ((long)b * p.H + h) * ((L + BLKK - 1) / BLKK) + t;
+    }
+    const uint16_t *v = reinterpret_cast<const uint16_t *>(p.v) + voff;
+
+    constexpr int TPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < BLKK * TPR / 256; i++) {
+        const int piece = tid + 256 * i;
+        const int row = piece / TPR, c8 = (piece % TPR) * 8;
+        const int tok = t * BLKK + row;
+        v4u raw = {0u, 0u, 0u, 0u};
+        if (tok < L) raw = *reinterpret_cast<const v4u *>(v + (long)tok * p.v_sl + c8);
+        *reinterpret_cast<v4u *>(&tile[row * LDT + c8]) = raw;
+    }
+    __syncthreads();
+
+    if constexpr (FP8) {
+        const float *amax = p.amax + ((long)b * p.H + h) * D;
+        if (t == 0 && tid < D) p.v_scale[((long)b * p.H + h) * D + tid] = amax[tid] / p.scale_max;
+        unsigned char *out = reinterpret_cast<unsigned char *>(p.out) + tile_idx * (long)(D * 64);
+#pragma unroll
+        for (int i = 0; i < D * 4 / 256; i++) {
+            const int piece = tid + 256 * i;
+            const int d = piece >> 2, pc = piece & 3;
+            const int ch = swz_chunk<64>(d, pc);                   // involution: physical <-> logical
+            const float am = amax[d];
+            const float recp = am > 0.0f ? p.scale_max / am : 0.0f;   // fused.cu:395
+            float f[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int tok = pv_token_of_position(16 * ch + j);
+                float x = ld16<DT>(tile[tok * LDT + d]) * recp;
+                f[j] = fminf(fmaxf(x, -448.0f), 448.0f);             // satfinite
+            }
+            v4u pk;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
+                word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
+                pk[w] = (unsigned)word;
+            }
+            *reinterpret_cast<v4u *>(out + d * 64 + pc * 16) = pk;
+        }
+    } else {
+        unsigned char *out = reinterpret_cast<unsigned char *>(p.out) + tile_idx * (long)(D * 128);
+#pragma unroll
+        for (int i = 0; i < D * 8 / 256; i++) {
+            const int piece = tid + 256 * i;
+            const int d = piece >> 3, pc = piece & 7;
+            const int ch = swz_chunk<128>(d, pc);
+            v4u pk;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned word = 0;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int tok = pv_token_of_position(8 * ch + 2 * w + e);
+                    uint16_t raw = tile[tok * LDT + d];
+                    if (DT != DT_F16) raw = f32_to_f16_rne(bf16_to_f32(raw));   // v.to(float16)
+                    word |= (unsigned)raw << (16 * e);
+                }
+                pk[w] = word;
+            }
+            *reinterpret_cast<v4u *>(out + d * 128 + pc * 16) = pk;
+        }
+    }
+}
+
+hipError_t launch_v_absmax(const PrepVParams &p, hipStream_t s)
+{
+    const int nslab = (p.L + kSlab - 1) / kSlab;
+    if (nslab <= 0 || p.B <= 0) return hipSuccess;
+    dim3 grid(nslab, p.H, p.B);
+#define SAGE_AM(D_, T_) hipLaunchKernelGGL((v_absmax_kernel<D_, T_>), grid, dim3(256), 0, s, p)
+    if (p.D == 128) { if (p.dtype == DT_F16) SAGE_AM(128, DT_F16); else SAGE_AM(128, DT_BF16); }
+    else if (p.D == 64) { if (p.dtype == DT_F16) SAGE_AM(64, DT_F16); else SAGE_AM(64, DT_BF16); }
+    else return hipErrorInvalidValue;
+#undef SAGE_AM
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_v(const PrepVParams &p, hipStream_t s)
+{
+    const int nt = (p.L + BLKK - 1) / BLKK;               // varlen: p.L = max_seqlen
+    if (nt <= 0 || p.B <= 0) return hipSuccess;
+    dim3 grid(nt, p.H, p.B);
+#define SAGE_PV(D_, T_, F_) hipLaunchKernelGGL((prep_v_kernel<D_, T_, F_>), grid, dim3(256), 0, s, p)
+    if (p.D == 128) {
+        if (p.fp8) { if (p.dtype == DT_F16) SAGE_PV(128, DT_F16, true); else SAGE_PV(128, DT_BF16, true); }
+        else       { if (p.dtype == DT_F16) SAGE_PV(128, DT_F16, false); else SAGE_PV(128, DT_BF16, false); }
+    } else if (p.D == 64) {
+        if (p.fp8) { if (p.dtype == DT_F16) SAGE_PV(64, DT_F16, true); else SAGE_PV(64, DT_BF16, true); }
+        else       { if (p.dtype == DT_F16) SAGE_PV(64, DT_F16, false); else SAGE_PV(64, DT_BF16, false); }
+    } else return hipErrorInvalidValue;
+#undef SAGE_PV
+    return hipGetLastError();
+}
+
+}  // namespace sage

@@ -1,0 +1,198 @@
+"""Host wrappers of the gfx950 quantisation kernels.
+
+Mirrors the reference's ``sageattention/quant.py`` (``per_block_int8`` :22, ``per_warp_int8``
+:105, ``per_channel_fp8`` :224) and the host halves of ``sageattention/triton/quant_per_block.py``
+:49, ``quant_per_block_varlen.py`` :60, ``quant_per_thread.py`` :154 -- same names, same argument
+meaning, same return shapes for the INT8 tensors and scales.  Like the reference, these
+functions allocate the outputs and the native op only writes into them.
+
+The one deliberate difference is V: the reference returns a transposed ``[B,H,D,ceil64(L)]``
+tensor whose token order is permuted for NVIDIA's ``mma.m16n8k32`` (quant.py:233,
+fused.cu:287-291).  That layout is private to (its quantiser, its kernel); ours is too: V is
+returned as the gfx950 *tile image* ``[B, H, ceil(L/64), D, 64]`` documented in
+``csrc/sage_prep_v.hip``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _cabi
+
+LOG2E = 1.44269504  # literal used by the reference (quant_per_block.py:87)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return _cabi.DTYPE_F16
+    if t.dtype == torch.bfloat16:
+        return _cabi.DTYPE_BF16
+    raise AssertionError("Input tensors must be in dtype of torch.float16 or torch.bfloat16")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dims(t: torch.Tensor, tensor_layout: str):
+    """(B, H, L, D, stride_b, stride_h, stride_l) of a 4-D tensor in HND / NHD layout."""
+    if tensor_layout == "HND":
+        B, H, L, D = t.shape
+        return B, H, L, D, t.stride(0), t.stride(1), t.stride(2)
+    if tensor_layout == "NHD":
+        B, L, H, D = t.shape
+        return B, H, L, D, t.stride(0), t.stride(2), t.stride(1)
+    raise ValueError(f"Unknown tensor layout: {tensor_layout}")
+
+
+def _aligned(t: torch.Tensor, elems: int) -> torch.Tensor:
+    """The kernels use 16-byte vector accesses; re-pack the rare tensor that is not aligned."""
+    ok = t.data_ptr() % 16 == 0 and t.stride(-1) == 1 and all(s % elems == 0 for s in t.stride()[:-1])
+    return t if ok else t.contiguous()
+
+
+def _squeeze_km(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torch.Tensor]:
+    if km is None:
+        return None
+    if km.dim() == 4:                      # keepdim mean: [B,H,1,D] (HND) / [B,1,H,D] (NHD)
+        km = km.squeeze(2 if tensor_layout == "HND" else 1)
+    return km.contiguous()
+
+
+def _quant(x, km, blk, warp, gran, is_key, style, pre_scale, tensor_layout, nslots):
+    x = _aligned(x, 8)
+    B, H, L, D, sb, sh, sl = _dims(x, tensor_layout)
+    out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    _, _, _, _, ob, oh, ol = _dims(out, tensor_layout)
+    scale = torch.empty((B, H, ((L + blk - 1) // blk) * nslots), dtype=torch.float32, device=x.device)
+    if km is not None:
+        assert km.dtype == x.dtype and km.shape == (B, H, D), "km must be [B, H, D] in the dtype of k"
+    rc = _cabi.load().sage_quant_qk_int8(
+        _p(x), _p(km), _p(out), _p(scale), B, H, L, D, sb, sh, sl, ob, oh, ol,
+        (H * D) if km is not None else 0, D if km is not None else 0,
+        blk, warp, gran, int(is_key), style, float(pre_scale), _dtype_code(x), _stream(x))
+    _cabi.check(rc, "sage_quant_qk_int8")
+    return out, scale
+
+
+def per_block_int8(q, k, km=None, BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None,
+                   tensor_layout: str = "HND", quantization_backend: str = "triton"):
+    """Per-block INT8 quantisation of q (128 rows) and k (64 rows); ``sm_scale*log2e`` is folded
+    into q.  Returns ``q_int8, q_scale[B,Hq,ceil(Lq/BLKQ)], k_int8, k_scale[B,Hkv,ceil(Lk/BLKK)]``.
+    ``quantization_backend`` selects the reference's rounding convention: "triton"
+    (quant_per_block.py:21-47) or "cuda" (quant.py:22-103 -> fused.cu:64-198)."""
+    D = q.size(-1)
+    if sm_scale is None:
+        sm_scale = D ** -0.5
+    style = {"triton": _cabi.QSTYLE_TRITON, "cuda": _cabi.QSTYLE_CUDA}[quantization_backend]
+    km = _squeeze_km(km, tensor_layout)
+    q_int8, q_scale = _quant(q, None, BLKQ, BLKQ, _cabi.GRAN_PER_BLOCK, False, style, sm_scale * LOG2E, tensor_layout, 1)
+    k_int8, k_scale = _quant(k, km, BLKK, BLKK, _cabi.GRAN_PER_BLOCK, True, style, 1.0, tensor_layout, 1)
+    return q_int8, q_scale, k_int8, k_scale
+
+
+def per_warp_int8(q, k, km=None, BLKQ: int = 128, WARPQ: int = 32, BLKK: int = 64, tensor_layout: str = "HND"):
+    """q: one scale per WARPQ rows inside each BLKQ block; k: one per BLKK rows with the mean
+    subtraction fused; sm_scale is NOT folded (quant.py:105-180)."""
+    km = _squeeze_km(km, tensor_layout)
+    q_int8, q_scale = _quant(q, None, BLKQ, WARPQ, _cabi.GRAN_PER_WARP, False, _cabi.QSTYLE_CUDA, 1.0, tensor_layout, BLKQ // WARPQ)
+    k_int8, k_scale = _quant(k, km, BLKK, BLKK, _cabi.GRAN_PER_BLOCK, True, _cabi.QSTYLE_CUDA, 1.0, tensor_layout, 1)
+    return q_int8, q_scale, k_int8, k_scale
+
+
+def per_thread_int8(q, k, km=None, BLKQ: int = 128, WARPQ: int = 32, BLKK: int = 64, WARPK: int = 64,
+                    sm_scale: Optional[float] = None, tensor_layout: str = "HND"):
+    """"per-thread" granularity (quant_per_thread.py:154-203): 8 q scales per WARPQ rows
+    (rows r, r+8, r+16, .. share), 4 k scales per WARPK tokens (tokens 8i+2t, 8i+2t+1 share)."""
+    km = _squeeze_km(km, tensor_layout)
+    q_int8, q_scale = _quant(q, None, BLKQ, WARPQ, _cabi.GRAN_PER_THREAD, False, _cabi.QSTYLE_TRITON_THREAD, 1.0,
+                             tensor_layout, (BLKQ // WARPQ) * 8)
+    k_int8, k_scale = _quant(k, km, BLKK, WARPK, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0,
+                             tensor_layout, (BLKK // WARPK) * 4)
+    return q_int8, q_scale, k_int8, k_scale
+
+
+def _cu_blocks(cu: torch.Tensor, blk: int) -> torch.Tensor:
+    lens = cu[1:] - cu[:-1]
+    return torch.nn.functional.pad(torch.cumsum((lens + blk - 1) // blk, dim=0), (1, 0), value=0).to(torch.int32)
+
+
+def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=None,
+                          BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None):
+    """Packed ``[sum L, H, D]`` per-block quantisation (quant_per_block_varlen.py:60-104).
+    ``km`` (``[1, H, D]`` or ``[H, D]``) is subtracted from k inside the kernel, rounded to the
+    input dtype exactly as the reference's ``k = k - km`` (core.py:432-434) does."""
+    q, k = _aligned(q, 8), _aligned(k, 8)
+    Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[-1]
+    if sm_scale is None:
+        sm_scale = D ** -0.5
+    nseq = cu_seqlens_q.shape[0] - 1
+    cu_q = cu_seqlens_q.to(torch.int32).contiguous()
+    cu_k = cu_seqlens_k.to(torch.int32).contiguous()
+    cu_qs, cu_ks = _cu_blocks(cu_q, BLKQ), _cu_blocks(cu_k, BLKK)
+    q_int8 = torch.empty(q.shape, dtype=torch.int8, device=q.device)
+    k_int8 = torch.empty(k.shape, dtype=torch.int8, device=k.device)
+    # one host sync, as in the reference (`torch.empty((cu_seqlens_q_scale[-1], h_qo))`, :75)
+    nq, nk = int(cu_qs[-1].item()), int(cu_ks[-1].item())
+    q_scale = torch.empty((nq, Hq), dtype=torch.float32, device=q.device)
+    k_scale = torch.empty((nk, Hkv), dtype=torch.float32, device=k.device)
+    if km is not None:
+        km = km.reshape(Hkv, D).contiguous()
+    lib = _cabi.load()
+    rc = lib.sage_quant_qk_int8_varlen(_p(q), None, _p(q_int8), _p(q_scale), _p(cu_q), _p(cu_qs), nseq, int(max_seqlen_q),
+                                       Hq, D, q.stride(0), q.stride(1), q_int8.stride(0), q_int8.stride(1), 0,
+                                       BLKQ, float(sm_scale * LOG2E), _dtype_code(q), _stream(q))
+    _cabi.check(rc, "sage_quant_qk_int8_varlen(q)")
+    rc = lib.sage_quant_qk_int8_varlen(_p(k), _p(km), _p(k_int8), _p(k_scale), _p(cu_k), _p(cu_ks), nseq, int(max_seqlen_k),
+                                       Hkv, D, k.stride(0), k.stride(1), k_int8.stride(0), k_int8.stride(1), D,
+                                       BLKK, 1.0, _dtype_code(k), _stream(k))
+    _cabi.check(rc, "sage_quant_qk_int8_varlen(k)")
+    return q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks
+
+
+def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = False
+                    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Per-channel FP8 (e4m3fn) quantisation of V fused with the transpose into the PV tile image
+    (reference: quant.py:224-293).  Returns ``(v_image uint8 [B,H,ceil(L/64),D,64],
+    v_scale fp32 [B,H,D], None)``.  ``smooth_v`` is not implemented on gfx950 (FP32 accumulators
+    make it unnecessary); passing True raises."""
+    if smooth_v:
+        raise NotImplementedError("smooth_v is not implemented in the gfx950 V pre-pass")
+    v = _aligned(v, 8)
+    B, H, L, D, sb, sh, sl = _dims(v, tensor_layout)
+    nt = (L + 63) // 64
+    v_image = torch.empty((B, H, nt, D, 64), dtype=torch.uint8, device=v.device)
+    v_scale = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
+    amax_ws = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
+    rc = _cabi.load().sage_prep_v_fp8(_p(v), _p(v_image), _p(v_scale), _p(amax_ws), B, H, L, D, sb, sh, sl,
+                                      float(scale_max), _dtype_code(v), _stream(v))
+    _cabi.check(rc, "sage_prep_v_fp8")
+    return v_image, v_scale, None
+
+
+def prep_v_fp16(v: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
+    """FP16-PV paths: ``v.to(float16)`` (core.py:297-298,613) fused with the transpose into the
+    tile image ``[B,H,ceil(L/64),D,64]`` (fp16)."""
+    v = _aligned(v, 8)
+    B, H, L, D, sb, sh, sl = _dims(v, tensor_layout)
+    v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.float16, device=v.device)
+    rc = _cabi.load().sage_prep_v_f16(_p(v), _p(v_image), B, H, L, D, sb, sh, sl, _dtype_code(v), _stream(v))
+    _cabi.check(rc, "sage_prep_v_f16")
+    return v_image
+
+
+def prep_v_fp16_varlen(v: torch.Tensor, cu_seqlens_k: torch.Tensor, cu_tiles: torch.Tensor, max_seqlen_k: int) -> torch.Tensor:
+    """Packed ``[sum L, H, D]`` V -> tile image ``[cu_tiles[-1], H, D, 64]`` fp16."""
+    v = _aligned(v, 8)
+    H, D = v.shape[1], v.shape[2]
+    ntiles = int(cu_tiles[-1].item())
+    v_image = torch.empty((ntiles, H, D, 64), dtype=torch.float16, device=v.device)
+    rc = _cabi.load().sage_prep_v_f16_varlen(_p(v), _p(v_image), _p(cu_seqlens_k), _p(cu_tiles), cu_seqlens_k.shape[0] - 1,
+                                             int(max_seqlen_k), H, D, v.stride(0), v.stride(1), _dtype_code(v), _stream(v))
+    _cabi.check(rc, "sage_prep_v_f16_varlen")
+    return v_image

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads, exports exactly what include/sage_gfx950.h declares, and rejects bad
+arguments before touching a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import util  # noqa: F401  (sys.path)
+from sageattention_amd import _cabi
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sage_gfx950.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"SAGE_API\s+[\w\s\*]+?\b(sage_\w+)\s*\(", txt)))
+
+
+def test_binding_covers_header():
+    assert declared_symbols() == sorted(_cabi.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    assert os.path.exists(_cabi.LIB_PATH), "run `python __graft_entry__.py` first"
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} not exported"
+    assert _cabi.load().sage_abi_version() == _cabi.ABI_VERSION
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _cabi.load()
+    buf = ctypes.create_string_buffer(4096)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    # head_dim 96 is rejected (the Python layer pads, core.py:260-271)
+    rc = lib.sage_quant_qk_int8(p, None, p, p, 1, 1, 16, 96, 0, 0, 96, 0, 0, 96, 0, 0, 128, 128, 1, 0, 0, 1.0, 0, None)
+    assert rc == -1 and b"head_dim" in lib.sage_last_error()
+    # misaligned pointer
+    rc = lib.sage_quant_qk_int8(p + 2, None, p, p, 1, 1, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 128, 128, 1, 0, 0, 1.0, 0, None)
+    assert rc == -1 and b"aligned" in lib.sage_last_error()
+    # Hq not divisible by Hkv
+    rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None)
+    assert rc == -1 and b"divisible" in lib.sage_last_error()
+    with pytest.raises(ValueError):
+        _cabi.check(rc, "x")
+
+
+def test_v_image_bytes():
+    lib = _cabi.load()
+    assert lib.sage_v_image_bytes(128, 1, 10) == 10 * 128 * 64
+    assert lib.sage_v_image_bytes(64, 0, 3) == 3 * 64 * 128
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_cabi, "_lib", None)
+    monkeypatch.setattr(_cabi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_cabi.SageLibraryError, match="no CPU/PyTorch fallback"):
+        _cabi.load()

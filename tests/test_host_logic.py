@@ -1,0 +1,55 @@
+"""CPU: host-side behaviour of the API mirror (error contract of the reference's core.py)."""
+import pytest
+import torch
+
+import util  # noqa: F401
+import sageattention
+import sageattention_amd as sa
+from sageattention_amd import core, shard
+
+
+def test_public_names_match_reference():
+    # /root/reference/sageattention/__init__.py:1-5
+    names = {"sageattn", "sageattn_varlen", "sageattn_qk_int8_pv_fp16_triton", "sageattn_qk_int8_pv_fp16_cuda",
+             "sageattn_qk_int8_pv_fp8_cuda", "sageattn_qk_int8_pv_fp8_cuda_sm90"}
+    assert names <= set(dir(sa)) and names <= set(dir(sageattention))
+    assert sageattention.sageattn is sa.sageattn
+
+
+def test_cpu_tensors_are_rejected_not_emulated():
+    q = torch.zeros(1, 1, 8, 64, dtype=torch.float16)
+    with pytest.raises(ValueError, match="Unsupported architecture"):
+        sa.sageattn(q, q, q)
+    for fn in (sa.sageattn_qk_int8_pv_fp8_cuda, sa.sageattn_qk_int8_pv_fp16_cuda, sa.sageattn_qk_int8_pv_fp16_triton):
+        with pytest.raises(AssertionError, match="must be on cuda"):
+            fn(q, q, q)
+
+
+def test_pad_head_dim_rules():
+    for d, want in ((32, 64), (64, 64), (96, 128), (128, 128)):
+        q = torch.zeros(1, 1, 4, d, dtype=torch.float16)
+        qq, kk, vv, og = core._pad_head_dim(q, q, q)
+        assert qq.shape[-1] == want and og == d
+    with pytest.raises(ValueError, match="Unsupported head_dim"):
+        core._pad_head_dim(*(torch.zeros(1, 1, 4, 160, dtype=torch.float16),) * 3)
+
+
+def test_smooth_k_and_lse_correction_shapes():
+    q = torch.randn(2, 4, 10, 64).half(); k = torch.randn(2, 2, 12, 64).half()
+    km, corr = core._smooth_k(q, k, "HND", True, True)
+    assert km.shape == (2, 2, 1, 64) and corr.shape == (2, 4, 10) and corr.dtype == torch.float32
+    km, corr = core._smooth_k(q.transpose(1, 2), k.transpose(1, 2), "NHD", True, True)
+    assert km.shape == (2, 1, 2, 64) and corr.shape == (2, 4, 10)
+    assert core._smooth_k(q, k, "HND", False, True) == (None, None)
+
+
+def test_shard_units_partition():
+    for B, H, g in ((2, 32, 1), (2, 32, 4), (3, 8, 8), (1, 48, 1)):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard.shard_range(B * H // g, r, world)
+                seen += list(range(lo, hi))
+            assert seen == list(range(B * H // g))
+    sizes = [shard.shard_range(64, r, 8) for r in range(8)]
+    assert all(hi - lo == 8 for lo, hi in sizes)

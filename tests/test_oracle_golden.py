@@ -1,0 +1,92 @@
+"""CPU: the oracle against the golden vectors produced by the REFERENCE (Triton kernels under the
+CPU interpreter, tests/golden/gen_golden.py) and against fp32 SDPA.  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import util
+
+DENSE = ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16", "causal_n384d128_f16", "pad_d96_n160_f16"]
+VARLEN = ["varlen_nc_d64_f16", "varlen_c_d64_f16", "varlen_c_d128_bf16"]
+
+
+def test_conversions_match_torch(oracle_mod):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(50000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 6e4)] +
+                       [np.array([0, -0.0, 65504, 65519.99, 65520, 2 ** -24, 2 ** -25, 448, 447.9, 464, -448, 2 ** -9, 2 ** -10, 0.0146, 0.0156], dtype=np.float32)])
+    t = torch.from_numpy(x)
+    assert (oracle_mod.convert(x, "f16") == t.to(torch.float16).view(torch.int16).numpy().view(np.uint16)).all()
+    assert (oracle_mod.convert(x, "bf16") == t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)).all()
+    xc = np.clip(x, -448, 448)
+    assert (oracle_mod.convert(xc, "e4m3") == torch.from_numpy(xc).to(torch.float8_e4m3fn).view(torch.uint8).numpy()).all()
+    # saturate-to-finite above 448 (cvt.rn.satfinite), unlike torch which produces NaN
+    assert oracle_mod.convert(np.array([1000.0, -1e9], dtype=np.float32), "e4m3").tolist() == [0x7E, 0xFE]
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_matches_reference(oracle_mod, name):
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, causal) = util.golden(name)
+    o, lse, aux = oracle_mod.sageattn_dense(z["q"], z["k"], z["v"], dt, is_causal=bool(causal), pv="f16_triton", return_lse=True)
+    # integer work is bit-exact
+    assert (aux["q8"] == z["q_int8"]).all() and (aux["k8"] == z["k_int8"]).all()
+    assert (aux["qs"] == z["q_scale"]).all() and (aux["ks"] == z["k_scale"]).all()
+    assert (aux["km"] == z["km"][:, :, 0, :]).all()
+    of, rf = util.f32(o, dt), util.f32(z["o"], dt)
+    # fp16: only summation order differs -> <= 1 ulp.  bf16: the CPU interpreter TRUNCATES fp32->bf16
+    # (triton/runtime/interpreter.py _convert_float, rounding_mode=None) where real Triton and this
+    # oracle round to nearest even -> up to 1 bf16 ulp (2^-7 relative).
+    tol = (2 ** -10 if dt == 0 else 2 ** -7) * max(1.0, float(np.abs(rf).max()))
+    assert np.abs(of - rf).max() <= tol
+    assert np.abs(lse - z["lse"]).max() < 1e-5
+    if dt == 0:
+        assert (o == z["o"]).mean() > 0.995
+
+
+@pytest.mark.parametrize("name", VARLEN)
+def test_varlen_matches_reference(oracle_mod, name):
+    z, (nseq, Hq, Hkv, total, _, D, dt, causal) = util.golden(name)
+    o = oracle_mod.sageattn_varlen(z["q"], z["k"], z["v"], dt, z["cu"], z["cu"], is_causal=bool(causal))
+    of, rf = util.f32(o, dt), util.f32(z["o"], dt)
+    tol = (2 ** -10 if dt == 0 else 2 ** -7) * max(1.0, float(np.abs(rf).max()))
+    assert np.abs(of - rf).max() <= tol
+
+
+def test_per_thread_quant_matches_reference(oracle_mod):
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden("per_thread_quant_d128_f16")
+    gq, nq = oracle_mod.group_index(Lq, "per_thread", "q", 128, 32)
+    gk, nk = oracle_mod.group_index(Lk, "per_thread", "k", 64, 64)
+    q8, qs = oracle_mod.quant_int8(z["q"], dt, gq, nq, style=oracle_mod.STYLE_TRITON_THREAD)
+    k8, ks = oracle_mod.quant_int8(z["k"], dt, gk, nk, style=oracle_mod.STYLE_TRITON_THREAD, mean=np.ascontiguousarray(z["km"][:, :, 0, :]))
+    assert (q8 == z["q_int8"]).all() and (k8 == z["k_int8"]).all()
+    assert (qs == z["q_scale"]).all() and (ks == z["k_scale"]).all()
+
+
+@pytest.mark.parametrize("pv,gran", [("f16_triton", "per_block"), ("f16", "per_warp"), ("f8", "per_warp"), ("f8", "per_thread"), ("f8", "per_block")])
+@pytest.mark.parametrize("causal", [False, True])
+def test_accuracy_vs_fp32_sdpa(oracle_mod, pv, gran, causal):
+    """Stated bounds vs fp32 SDPA on randn inputs with a large per-channel K bias (where smoothing
+    matters): FP16 PV cos >= 0.9995; FP8 PV cos >= 0.9990 -- e4m3 P and V carry
+    2^-4 relative rounding error each and randn V averages towards zero, so the cosine is lower at
+    equal RMSE.  Relative RMSE (RMSE / RMS(truth)) <= 2% (FP16 PV) / 5% (FP8 PV); measured 1.1-1.3% / 3.3-3.8%."""
+    torch.manual_seed(11)
+    B, Hq, Hkv, L, D = 1, 4, 2, 320, 128
+    q = torch.randn(B, Hq, L, D).half()
+    k = (torch.randn(B, Hkv, L, D) + 4.0 * torch.randn(1, Hkv, 1, D)).half()
+    v = torch.randn(B, Hkv, L, D).half()
+    o, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 0, is_causal=causal, pv=pv, qk_quant_gran=gran)
+    truth = util.sdpa_f32(q, k, v, causal).numpy()
+    of = util.f32(o, 0)
+    assert util.cos_sim(of, truth) >= (0.9990 if pv == "f8" else 0.9995)
+    assert util.rmse(of, truth) / float(np.sqrt((truth ** 2).mean())) <= (0.05 if pv == "f8" else 0.02)
+
+
+def test_two_level_equals_single_level_to_rounding(oracle_mod):
+    torch.manual_seed(3)
+    q = torch.randn(1, 2, 200, 64).half(); k = torch.randn(1, 2, 200, 64).half(); v = torch.randn(1, 2, 200, 64).half()
+    _, _, aux = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 0, pv="f8", qk_quant_gran="per_warp")
+    outs = []
+    for mode in (oracle_mod.PV_F8_TWO_LEVEL, oracle_mod.PV_F8_SINGLE):
+        o, _ = oracle_mod.attn(aux["q8"], aux["k8"], aux["v8"], aux["qs"], aux["gq"], aux["ks"], aux["gk"], causal=False,
+                               c=aux["c"], pv_mode=mode, out_dtype=0, v_scale=aux["vs"])
+        outs.append(util.f32(o, 0))
+    assert np.abs(outs[0] - outs[1]).max() <= 2 ** -10
