@@ -167,7 +167,7 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
-                   qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None):
+                   qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -198,7 +198,7 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
         k8, ks = quant_int8(k, dtype, gk, nk, style=style, mean=km)
         c = 1.0
     elif qk_quant_gran == "per_warp":
-        gq, nq = group_index(Lq, "per_warp", "q", 128, 32)
+        gq, nq = group_index(Lq, "per_warp", "q", 128, warpq)     # WARPQ 32, or 16 (core.py:602)
         gk, nk = group_index(Lk, "per_warp", "k", 64, 64)
         q8, qs = quant_int8(q, dtype, gq, nq, style=STYLE_CUDA)
         k8, ks = quant_int8(k, dtype, gk, nk, style=STYLE_CUDA, mean=km)

@@ -153,7 +153,8 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     # the K mean is host plumbing (torch, as in the reference): hand the oracle the very same km
     km = util.bits(k.to(DEV).mean(dim=2))
     o_bits, lse_ref, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal,
-                                            pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km)
+                                            pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km,
+                                            warpq=16 if (pv == "f16_two" and D == 128) else 32)   # core.py:602
     # same operands through the HIP kernels
     fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
     accum = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}[pv]
@@ -293,6 +294,7 @@ def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
     o = fn(q, k, v, is_causal=causal)
     # (1) exact linearity in V under power-of-two scaling (per-channel V scales absorb it)
     o2 = fn(q, k, v * 2, is_causal=causal)
+    REPORT[f"full/{tag}/v2_maxdiff"] = float((o2.float() - 2 * o.float()).abs().max())
     assert torch.equal(o2, o * 2), "V -> 2V must double the output bit-exactly"
     # (2) batch*head shard invariance: a slice of the heads gives the same bits (multi-GPU sharding)
     hs = slice(q.size(1) // 2, q.size(1) // 2 + 4)
@@ -310,6 +312,9 @@ def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
 def test_config2_fp16_pv_b2h32n4096d128_causal():
     """BASELINE.json configs[1]."""
     q, k, v = (t.to(DEV) for t in rand_qkv(2, 32, 32, 4096, 4096, 128, 0, seed=2))
+    # keep V out of the fp16 subnormal range: v_mfma_f32_32x32x16_f16 flushes subnormal fp16 inputs,
+    # so a subnormal v (|v| < 2^-14, ~5e-5 of randn samples) contributes 0 while 2v contributes 2v
+    v = torch.where(v.abs() < 2.0 ** -12, torch.full_like(v, 2.0 ** -12), v)
     _props(lambda *a, **kw: sa.sageattn_qk_int8_pv_fp16_cuda(*a, pv_accum_dtype="fp32", **kw), q, k, v, True, "c2_f16", 0.9995, 0.02)
 
 
