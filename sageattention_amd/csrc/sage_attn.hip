@@ -23,7 +23,27 @@
 #include "sage_common.h"
 #include "sage_kernels.h"
 
+// ---- build-time variant switches (A/B-tested on the GPU; see DESIGN.md "kernel ladder") ----------
+#ifndef SAGE_MAGIC      // seed the int32 QK^T accumulator with 0x4B400000 so the result bits ARE the float
+#define SAGE_MAGIC 1    // 12582912 + dot: no v_cvt_f32_i32, the offset folds into the exp2 FMA addend
+#endif
+#ifndef SAGE_GLDS       // K/V tiles by LDS-DMA (global_load_lds_dwordx4) instead of VGPR staging
+#define SAGE_GLDS 1
+#endif
+#ifndef SAGE_MXPV       // FP8 PV on v_mfma_scale_f32_32x32x64_f8f6f4 with unit E8M0 scales (2x rate)
+#define SAGE_MXPV 1
+#endif
+#ifndef SAGE_SETPRIO    // s_setprio 1 around MFMA clusters
+#define SAGE_SETPRIO 0
+#endif
+#ifndef SAGE_ABL        // timing-only ablations (WRONG results): 1 no exp, 2 no PV MFMA, 4 no QK MFMA,
+#define SAGE_ABL 0      // 8 no O update, 16 no max/sum, 32 no barrier
+#endif
+
 namespace sage {
+
+constexpr int kMagicI = 0x4B400000;          // bits of 12582912.0f = 2^23 + 2^22: ulp 1 over +-2^22
+constexpr float kMagicF = 12582912.0f;
 
 template <int D, bool PV_FP8> struct TileCfg {
     static constexpr int K_ROW_BYTES = D;                       // int8
@@ -140,9 +160,39 @@ sage_attn_kernel(const AttnParams p)
     // ---- tile staging: global -> VGPR -> LDS -------------------------------------------------
     const unsigned char *kbase = reinterpret_cast<const unsigned char *>(p.k) + k_off;
     const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v);
+#if SAGE_GLDS
+    // LDS-DMA: every wave-instruction moves 64 x 16 B = 1 KiB; the LDS destination is lane-linear
+    // (M0 base + lane*16), so the XOR swizzle of the K image goes on the per-lane SOURCE address.
+    // Key rows past Lk are clamped to the last valid row (their scores are masked anyway).
+    auto issue_loads = [&](int t, int buf) {
+        unsigned char *ks = smem + buf * C::STAGE_BYTES;
+        unsigned char *vs = ks + C::K_TILE_BYTES;
+        constexpr int CPR = D / 16;
+        constexpr int KP = C::K_TILE_BYTES / 1024, VP = C::V_TILE_BYTES / 1024;   // 1-KiB pieces
+#pragma unroll
+        for (int i = 0; i < KP / 4; i++) {
+            const int pc = wave * (KP / 4) + i;
+            const int e = pc * 64 + lane;                      // 16-B slot index inside the tile
+            const int row = e / CPR, phys = e % CPR;
+            int key = t * BLKK + row;
+            key = key < Lk ? key : Lk - 1;
+            const unsigned char *src = kbase + (long)key * p.k_sl + swz_chunk<D>(row, phys) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
+        }
+        const unsigned char *vt = vbase + (v_tile0 + (long)t * v_tstride) * (long)C::V_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < VP / 4; i++) {
+            const int pc = wave * (VP / 4) + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(vs + pc * 1024), 16, 0, 0);
+        }
+    };
+    auto write_lds = [&](int) {};
+#else
     v4u kreg[C::K_LD], vreg[C::V_LD];
 
-    auto issue_loads = [&](int t) {
+    auto issue_loads = [&](int t, int) {
         // K tile: 64 rows x D bytes; thread -> (row, 16-B chunk), 16B*K_LD contiguous per thread
         constexpr int CPR = D / 16;                              // chunks per row
 #pragma unroll
@@ -172,6 +222,7 @@ sage_attn_kernel(const AttnParams p)
         for (int i = 0; i < C::V_LD; i++)
             *reinterpret_cast<v4u *>(vs + (i * 256 + tid) * 16) = vreg[i];   // image is pre-swizzled
     };
+#endif
 
     // ---- running state -------------------------------------------------------------------------
     v16f o[C::DT];
@@ -182,8 +233,13 @@ sage_attn_kernel(const AttnParams p)
     float m_run = kNegBig, l_run = 0.0f;
     constexpr float OFF = PV_FP8 ? kFp8Offset : 0.0f;
 
+#if SAGE_MAGIC
+    v16i magic;
+#pragma unroll
+    for (int i = 0; i < 16; i++) magic[i] = kMagicI;
+#endif
     if (n_tiles > 0) {
-        issue_loads(0);
+        issue_loads(0, 0);
         write_lds(0);
     }
     __syncthreads();
@@ -191,7 +247,7 @@ sage_attn_kernel(const AttnParams p)
     for (int t = 0; t < n_tiles; t++) {
         const int cur = t & 1;
         const bool more = (t + 1) < n_tiles;
-        if (more) issue_loads(t + 1);
+        if (more) issue_loads(t + 1, cur ^ 1);
 
         // wave-uniform: does this wave have any unmasked key in the tile?
         const bool active = !CAUSAL || (t * BLKK <= row0 + 31);
@@ -201,17 +257,42 @@ sage_attn_kernel(const AttnParams p)
 
             // ---- S^T = K Q^T (int8 -> int32) ----
             v16i s[2];
+#if SAGE_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) s[sub][i] = 0;
                 const int krow = sub * 32 + n;
 #pragma unroll
                 for (int kk = 0; kk < C::KSTEPS; kk++) {
                     const v4i a = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                    s[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], s[sub], 0, 0, 0);
+#if SAGE_ABL & 4
+                    if (kk == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) s[sub][i] = qf[0][i & 3] + a[i & 3];
+                    }
+#elif SAGE_MAGIC
+                    s[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], kk == 0 ? magic : s[sub], 0, 0, 0);
+#else
+                    v16i z;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) z[i] = 0;
+                    s[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], kk == 0 ? z : s[sub], 0, 0, 0);
+#endif
                 }
             }
+#if SAGE_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            // score register -> float.  With SAGE_MAGIC the accumulator bits already are the float
+            // (kMagicF + dot), exact for |dot| < 2^22 (max |dot| = 128*127*127 < 2^21).
+#if SAGE_MAGIC
+#define SAGE_SF(sub, i) __int_as_float(s[sub][i])
+            constexpr float SHIFT = kMagicF;
+#else
+#define SAGE_SF(sub, i) ((float)s[sub][i])
+            constexpr float SHIFT = 0.0f;
+#endif
 
             // ---- scales: c[sel] multiplies the raw int32 score into the log2 domain ----
             float c0, c1;
@@ -221,30 +302,40 @@ sage_attn_kernel(const AttnParams p)
             } else {
                 c0 = c1 = qsc * ks_ptr[(long)t * ks_tstride];
             }
+            const float sh0 = SHIFT * c0, sh1 = SHIFT * c1;   // shift of the magic seed in the log2 domain
 
             // ---- online softmax ----
             const bool need_mask = (CAUSAL && (t * BLKK + BLKK - 1 > row0)) || (t * BLKK + BLKK > Lk);
             float pf[2][16];
             float m_new;
             if (!need_mask) {
-                float mx0 = kNegBig, mx1 = kNegBig;
+                float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
                 for (int sub = 0; sub < 2; sub++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        pf[sub][i] = (float)s[sub][i];
-                        if (KTHREAD && (i & 2)) mx1 = fmaxf(mx1, pf[sub][i]);
-                        else mx0 = fmaxf(mx0, pf[sub][i]);
+#if !(SAGE_ABL & 16)
+                        if (KTHREAD && (i & 2)) mx1 = fmaxf(mx1, SAGE_SF(sub, i));
+                        else mx0 = fmaxf(mx0, SAGE_SF(sub, i));
+#else
+                        if (i == 0) { mx0 = SAGE_SF(sub, 0); mx1 = SAGE_SF(sub, 2); }
+#endif
                     }
-                float mx = KTHREAD ? fmaxf(mx0 * c0, mx1 * c1) : mx0 * c0;
+                float mx = __builtin_fmaf(mx0, c0, -sh0);
+                if (KTHREAD) mx = fmaxf(mx, __builtin_fmaf(mx1, c1, -sh1));
                 mx = pair_max(mx);
                 m_new = fmaxf(m_run, mx - OFF);
+                const float a0 = -(m_new + sh0), a1 = -(m_new + sh1);
 #pragma unroll
                 for (int sub = 0; sub < 2; sub++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float cc = (KTHREAD && (i & 2)) ? c1 : c0;
-                        pf[sub][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(pf[sub][i], cc, -m_new));
+                        const bool hi = KTHREAD && (i & 2);
+#if SAGE_ABL & 1
+                        pf[sub][i] = __builtin_fmaf(SAGE_SF(sub, i), hi ? c1 : c0, hi ? a1 : a0);
+#else
+                        pf[sub][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(SAGE_SF(sub, i), hi ? c1 : c0, hi ? a1 : a0));
+#endif
                     }
             } else {
                 float mx = -INFINITY;
@@ -252,10 +343,10 @@ sage_attn_kernel(const AttnParams p)
                 for (int sub = 0; sub < 2; sub++)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float cc = (KTHREAD && (i & 2)) ? c1 : c0;
+                        const bool hi = KTHREAD && (i & 2);
                         const int key = t * BLKK + sub * 32 + crow(i, g);
                         const bool ok = (key < Lk) && (!CAUSAL || key <= my_row);
-                        const float v = ok ? (float)s[sub][i] * cc : -INFINITY;
+                        const float v = ok ? __builtin_fmaf(SAGE_SF(sub, i), hi ? c1 : c0, hi ? -sh1 : -sh0) : -INFINITY;
                         pf[sub][i] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -267,13 +358,18 @@ sage_attn_kernel(const AttnParams p)
                     for (int i = 0; i < 16; i++)
                         pf[sub][i] = __builtin_amdgcn_exp2f(pf[sub][i] - m_new);
             }
+#undef SAGE_SF
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             float rs = 0.0f;
+#if !(SAGE_ABL & 16)
 #pragma unroll
             for (int sub = 0; sub < 2; sub++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) rs += pf[sub][i];
+#else
+            rs = pf[0][0] + pf[1][5];
+#endif
             l_run = l_run * alpha + rs;          // lane-partial; the pair is summed in the epilogue
 
             // ---- P -> low precision, already in PV B-operand order ----
@@ -301,23 +397,47 @@ sage_attn_kernel(const AttnParams p)
                     const unsigned char *vr = vs + drow * 64;
                     const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
                     const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-                    const long a0 = (long)(((unsigned long)va[1] << 32) | va[0]);
-                    const long a1 = (long)(((unsigned long)va[3] << 32) | va[2]);
-                    const long a2 = (long)(((unsigned long)vb[1] << 32) | vb[0]);
-                    const long a3 = (long)(((unsigned long)vb[3] << 32) | vb[2]);
                     v16f acc;
                     if (TWO_LEVEL) {
 #pragma unroll
                         for (int i = 0; i < 16; i++) acc[i] = 0.0f;
                     } else acc = o[dt];
+#if SAGE_SETPRIO
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+#if SAGE_MXPV
+                    // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0) per d tile:
+                    // same products, same FP32 accumulation, twice the rate of 4 x 32x32x16
+                    const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
+                    const v8i bv = {(int)pb[0], (int)(pb[0] >> 32), (int)pb[1], (int)(pb[1] >> 32),
+                                    (int)pb[2], (int)(pb[2] >> 32), (int)pb[3], (int)(pb[3] >> 32)};
+#if SAGE_ABL & 2
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc[i] += __int_as_float(av[i & 7] ^ bv[i & 7]);
+#else
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#endif
+#else
+                    const long a0 = (long)(((unsigned long)va[1] << 32) | va[0]);
+                    const long a1 = (long)(((unsigned long)va[3] << 32) | va[2]);
+                    const long a2 = (long)(((unsigned long)vb[1] << 32) | vb[0]);
+                    const long a3 = (long)(((unsigned long)vb[3] << 32) | vb[2]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, pb[0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, pb[1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2, pb[2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a3, pb[3], acc, 0, 0, 0);
+#endif
+#if SAGE_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+#if SAGE_ABL & 8
+                    o[dt][dt] += acc[0] + acc[5] + acc[10] + acc[15];
+#else
                     if (TWO_LEVEL) {
 #pragma unroll
                         for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
                     } else o[dt] = acc;
+#endif
                 }
             } else {
                 v8h pb[4];
@@ -350,7 +470,11 @@ sage_attn_kernel(const AttnParams p)
         }
 
         if (more) write_lds(cur ^ 1);
+#if SAGE_ABL & 32
+        __builtin_amdgcn_s_waitcnt(0);
+#else
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
@@ -410,7 +534,13 @@ static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
 {
     using C = TileCfg<D, PV_FP8>;
     auto kern = sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL>;
-    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
+#ifdef SAGE_LDS_MIN_BYTES   // experiments: cap workgroups per CU through the LDS budget
+    constexpr int lds = C::LDS_BYTES > SAGE_LDS_MIN_BYTES ? C::LDS_BYTES : SAGE_LDS_MIN_BYTES;
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#else
+    constexpr int lds = C::LDS_BYTES;
+#endif
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
