@@ -295,7 +295,12 @@ def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
     # (1) exact linearity in V under power-of-two scaling (per-channel V scales absorb it)
     o2 = fn(q, k, v * 2, is_causal=causal)
     REPORT[f"full/{tag}/v2_maxdiff"] = float((o2.float() - 2 * o.float()).abs().max())
-    assert torch.equal(o2, o * 2), "V -> 2V must double the output bit-exactly"
+    # exact wherever the output is a normal number of its dtype; in the subnormal range the final
+    # rounding has a fixed quantum (2^-24 for fp16), so round(2x) may differ from 2*round(x) by one
+    tiny = 2.0 ** -13 if o.dtype == torch.float16 else 2.0 ** -120
+    normal = o.abs() >= tiny
+    assert torch.equal(o2[normal], (o * 2)[normal]), "V -> 2V must double the output bit-exactly"
+    assert (o2.float() - 2 * o.float()).abs().max().item() <= 2.0 ** -23
     # (2) batch*head shard invariance: a slice of the heads gives the same bits (multi-GPU sharding)
     hs = slice(q.size(1) // 2, q.size(1) // 2 + 4)
     o_sh = fn(q[1:2, hs], k[1:2, hs], v[1:2, hs], is_causal=causal)
