@@ -43,9 +43,13 @@ CONFIGS = {
     "c5": dict(B=2, H=48, Hkv=48, N=17776, D=64, causal=False, pv="fp8", dtype="bf16",
                workload="CogVideoX1.5-5B shaped sageattn() B=2 H=48 N=17776 D=64 non-causal (BASELINE.json configs[4])"),
 }
-# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, non-scaled fp8 = bf16
-# rate (2.5 PF), int8 = 2x bf16 (5.0 POPS).  Half of the FLOPs are INT8 (QK^T), half FP8/FP16 (PV):
-PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 2500.0, 2500.0
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, fp8 5.0 PF (the MX-scaled
+# instruction the PV step issues; the non-scaled fp8 MFMA runs at the bf16 rate), int8 = 2x bf16 = 5.0 POPS.
+# Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
+PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
+# HBM bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
+# gfx950 correction per MI355X_MICROARCH.md); see profiles/r1_run2_pmc_c3_v1kernel.txt
+PMC_TRAFFIC_BYTES = {"c3": 336.9e6}
 
 
 def blended_peak(pv: str) -> float:
@@ -225,9 +229,10 @@ def main():
         "config": {"workload": cfg["workload"], "global_batch": cfg["B"] * world, "heads": cfg["H"], "seq_len": cfg["N"],
                    "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world}, no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get(args.config),
+                     "traffic_note": "HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), algorithmic 335.5e6" if args.config in PMC_TRAFFIC_BYTES else None,
                      "kernel": "sage_attn_kernel", "avg_launch_ms": round(kern_ms, 4),
-                     "peak_note": "harmonic blend of dense INT8 (5.0 POPS, QK^T half) and non-scaled FP8/FP16 MFMA (2.5 PF, PV half)"},
+                     "peak_note": "harmonic blend of the dense MFMA peaks of the two halves: INT8 5.0 POPS (QK^T) and " + ("FP8 5.0 PF (MX-scaled instruction)" if cfg["pv"] == "fp8" else "FP16 2.5 PF") + " (PV)"},
         "end_to_end": {"ms_per_call": round(wall_e / e2e_steps * 1e3, 4),
                        "tflops": round(fl * world / (wall_e / e2e_steps) / 1e12, 2),
                        "what": "sageattn(): K mean + INT8 Q/K quant + V pre-pass + attention"},
