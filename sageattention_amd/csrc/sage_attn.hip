@@ -28,6 +28,7 @@
 #include "sage_common.h"
 #include "sage_kernels.h"
 #include <climits>
+#include <type_traits>
 
 // ---- build-time switches used for the A/B ladder in DESIGN.md ------------------------------------
 #ifndef SAGE_GLDS       // K/V tiles by LDS-DMA instead of VGPR staging (+4%)
@@ -38,6 +39,11 @@
 #endif
 #ifndef SAGE_NH_F8      // 64-key images per iteration (2 = 128-key tiles: spills at D=128 today)
 #define SAGE_NH_F8 1
+#endif
+
+#ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow: 3 (<= 168 VGPRs,
+                        // +3.5% measured) wherever that does not spill, i.e. everything except FP16 PV at D=128 and FP8 single-level per-thread
+#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL) ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2)
 #endif
 
 namespace sage {
@@ -58,7 +64,7 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL))
 sage_attn_kernel(const AttnParams p)
 {
     using C = TileCfg<D, PV_FP8, NH>;
@@ -163,20 +169,39 @@ sage_attn_kernel(const AttnParams p)
     // (M0 base + lane*16), so the XOR swizzle of the K image goes on the per-lane SOURCE address.
     // Key rows past Lk are clamped to the last valid row, V images past the last one to the last
     // image (their probabilities are exactly zero: masked scores).
+    constexpr int KP = C::K_TILE_BYTES / 1024, VP = C::V_IMG_BYTES / 1024;   // 1-KiB pieces
+    // per-lane source offsets are loop-invariant: tile base pointers advance in SGPRs, so a full
+    // tile costs no VALU address arithmetic per iteration
+    unsigned koff[KP / 4];
+#pragma unroll
+    for (int i = 0; i < KP / 4; i++) {
+        const int e = (wave * (KP / 4) + i) * 64 + lane;       // 16-B slot index inside the tile
+        const int row = e / CPR, phys = e % CPR;
+        koff[i] = (unsigned)(row * (int)p.k_sl + swz_chunk<D>(row, phys) * 16);
+    }
     auto issue_loads = [&](int it, int buf) {
         unsigned char *ks = smem + buf * C::STAGE_BYTES;
         unsigned char *vs = ks + C::K_TILE_BYTES;
-        constexpr int KP = C::K_TILE_BYTES / 1024, VP = C::V_IMG_BYTES / 1024;   // 1-KiB pieces
+        const unsigned char *kt = kbase + (long)it * KT * p.k_sl;
+        if (it * KT + KT <= Lk) {
 #pragma unroll
-        for (int i = 0; i < KP / 4; i++) {
-            const int pc = wave * (KP / 4) + i;
-            const int e = pc * 64 + lane;                      // 16-B slot index inside the tile
-            const int row = e / CPR, phys = e % CPR;
-            int key = it * KT + row;
-            key = key < Lk ? key : Lk - 1;
-            const unsigned char *src = kbase + (long)key * p.k_sl + swz_chunk<D>(row, phys) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
+            for (int i = 0; i < KP / 4; i++) {
+                const int pc = wave * (KP / 4) + i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kt + koff[i]),
+                                                 (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KP / 4; i++) {
+                const int pc = wave * (KP / 4) + i;
+                const int e = pc * 64 + lane;
+                const int row = e / CPR, phys = e % CPR;
+                int key = it * KT + row;
+                key = key < Lk ? key : Lk - 1;
+                const unsigned char *src = kbase + (long)key * p.k_sl + swz_chunk<D>(row, phys) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
@@ -239,7 +264,26 @@ sage_attn_kernel(const AttnParams p)
     float m_run = kNegBig, l_run = 0.0f;
     constexpr float OFF = PV_FP8 ? kFp8Offset : 0.0f;
 
+    // K scales of the current iteration, loaded one iteration ahead and BEFORE that iteration's
+    // LDS-DMA is issued: an ordinary VMEM load issued after the DMA would make its s_waitcnt
+    // vmcnt(0) drain the in-flight tile too (vmcnt retires in order).
+    float ksc[NH][2];
+    auto load_kscales = [&](int it, float (&dst)[NH][2]) {
+#pragma unroll
+        for (int hh = 0; hh < NH; hh++) {
+            int tk = it * NH + hh;
+            tk = tk < ntk_all ? tk : ntk_all - 1;
+            const long tb = (long)tk * ks_tstride;
+            if (KTHREAD) {      // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83)
+                dst[hh][0] = ks_ptr[tb + 2 * g];
+                dst[hh][1] = ks_ptr[tb + 2 * g + 1];
+            } else {
+                dst[hh][0] = dst[hh][1] = ks_ptr[tb];
+            }
+        }
+    };
     if (n_iters > 0) {
+        load_kscales(0, ksc);
         issue_loads(0, 0);
         write_lds(0);
     }
@@ -249,7 +293,11 @@ sage_attn_kernel(const AttnParams p)
     for (int it = 0; it < n_iters; it++) {
         const int cur = it & 1;
         const bool more = (it + 1) < n_iters;
-        if (more) issue_loads(it + 1, cur ^ 1);
+        float ksc_next[NH][2];
+        if (more) {
+            load_kscales(it + 1, ksc_next);
+            issue_loads(it + 1, cur ^ 1);
+        }
 
         // number of 64-key halves with at least one key this wave may attend to (wave-uniform)
         int nact = 0;
@@ -284,13 +332,8 @@ sage_attn_kernel(const AttnParams p)
             float cs[NH][2];
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) {
-                const long tb = (long)(it * NH + (hh < nact ? hh : 0)) * ks_tstride;
-                if (KTHREAD) {  // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83)
-                    cs[hh][0] = qsc * ks_ptr[tb + 2 * g];
-                    cs[hh][1] = qsc * ks_ptr[tb + 2 * g + 1];
-                } else {
-                    cs[hh][0] = cs[hh][1] = qsc * ks_ptr[tb];
-                }
+                cs[hh][0] = qsc * ksc[hh][0];
+                cs[hh][1] = qsc * ksc[hh][1];
             }
 
             // ---- online softmax over the iteration's keys ----
@@ -341,14 +384,14 @@ sage_attn_kernel(const AttnParams p)
             // P for chunk c (16 keys) of half hh = registers 8u..8u+7 of S^T tile 2hh + (c>>1):
             // exactly the order of the PV B operand (sage_common.h)
             float rs = 0.0f;
-            auto p_chunk = [&](int hh, int c, float (&e)[8]) {
+            auto p_chunk = [&](auto masked, int hh, int c, float (&e)[8]) {
                 const int sb = 2 * hh + (c >> 1), r0 = (c & 1) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int i = r0 + j;
                     const float cc = cs[hh][(KTHREAD && (i & 2)) ? 1 : 0];
                     float v = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[sb][i], cc, -m_new));
-                    if (!full) {
+                    if constexpr (decltype(masked)::value) {
                         const int key = it * KT + sb * 32 + crow(i, g);
                         const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= my_row);
                         v = ok ? v : 0.0f;
@@ -360,19 +403,23 @@ sage_attn_kernel(const AttnParams p)
 
             if constexpr (PV_FP8) {
                 int pw[NH][8];                   // 32 fp8 per 64-key half = B operand of one K=64 MFMA
+                auto build_p = [&](auto masked) {
 #pragma unroll
-                for (int hh = 0; hh < NH; hh++)
+                    for (int hh = 0; hh < NH; hh++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        float e[8];
-                        p_chunk(hh, c, e);
-                        int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], 0, false);
-                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
-                        int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], 0, false);
-                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
-                        pw[hh][2 * c] = w0;
-                        pw[hh][2 * c + 1] = w1;
-                    }
+                        for (int c = 0; c < 4; c++) {
+                            float e[8];
+                            p_chunk(masked, hh, c, e);
+                            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], __float_as_int(e[0]), false);   // high half is overwritten next
+                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
+                            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], __float_as_int(e[4]), false);
+                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
+                            pw[hh][2 * c] = w0;
+                            pw[hh][2 * c + 1] = w1;
+                        }
+                };
+                if (full) build_p(std::false_type{});
+                else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;      // lane-partial; the pair is summed in the epilogue
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) {
@@ -410,15 +457,19 @@ sage_attn_kernel(const AttnParams p)
                 }
             } else {
                 v8h pb[NH][4];
+                auto build_p = [&](auto masked) {
 #pragma unroll
-                for (int hh = 0; hh < NH; hh++)
+                    for (int hh = 0; hh < NH; hh++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        float e[8];
-                        p_chunk(hh, c, e);
+                        for (int c = 0; c < 4; c++) {
+                            float e[8];
+                            p_chunk(masked, hh, c, e);
 #pragma unroll
-                        for (int j = 0; j < 8; j++) pb[hh][c][j] = (_Float16)e[j];
-                    }
+                            for (int j = 0; j < 8; j++) pb[hh][c][j] = (_Float16)e[j];
+                        }
+                };
+                if (full) build_p(std::false_type{});
+                else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) {
@@ -447,7 +498,11 @@ sage_attn_kernel(const AttnParams p)
             }
         }
 
-        if (more) write_lds(cur ^ 1);
+        if (more) {
+            write_lds(cur ^ 1);
+#pragma unroll
+            for (int hh = 0; hh < NH; hh++) { ksc[hh][0] = ksc_next[hh][0]; ksc[hh][1] = ksc_next[hh][1]; }
+        }
         __syncthreads();
     }
 
