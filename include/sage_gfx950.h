@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 1
+#define SAGE_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -100,20 +100,39 @@ SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *
                               int blk, float pre_scale, int dtype, void *stream);
 
 /*
- * V pre-pass, FP8: per-channel scale + e4m3 + transpose into the gfx950 PV tile image.
- * Replaces: transpose_pad_permute_cuda + scale_fuse_quant_cuda (csrc/fused/fused.h:57-75,
- *           quant.py:224-293).  v is [B,H,L,D] (strides), v_image receives
- *           sage_v_image_bytes(D, 1, B*H*ceil(L/64)) bytes, v_scale [B,H,D] fp32,
- *           amax_ws [B,H,D] fp32 scratch (zeroed by the call).  scale_max = 448 (e4m3 max).
+ * Workspace size, in floats, of the per-channel statistics pass used by sage_channel_mean and
+ * sage_prep_v_fp8 for a [B,H,L,D] tensor: partial (max,min,sum) per 512-token slab + the final block.
  */
-SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *amax_ws,
+SAGE_API int64_t sage_stats_ws_floats(int B, int H, int L, int D);
+
+/*
+ * Mean over the sequence of x[B,H,L,D] (strides), written in the input dtype to mean_out[B,H,D]
+ * (fp32 accumulation, one rounding; deterministic order).  Replaces the torch reduction
+ * `km = k.mean(dim=seq)` (core.py:280,584,773; `k.mean(dim=0)` for varlen with B=1, H stride D)
+ * and `vm = v.mean(...)` of sub_mean (quant.py:216).  ws: sage_stats_ws_floats(B,H,L,D) floats.
+ */
+SAGE_API int sage_channel_mean(const void *x, void *mean_out, float *ws, int B, int H, int L, int D,
+                               int64_t x_sb, int64_t x_sh, int64_t x_sl, int dtype, void *stream);
+
+/*
+ * V pre-pass, FP8: per-channel scale + e4m3 + transpose into the gfx950 PV tile image.
+ * Replaces: transpose_pad_permute_cuda + scale_fuse_quant_cuda / mean_scale_fuse_quant_cuda
+ *           (csrc/fused/fused.h:57-75, quant.py:224-293).  v is [B,H,L,D] (strides), v_image receives
+ *           sage_v_image_bytes(D, 1, B*H*ceil(L/64)) bytes, v_scale [B,H,D] fp32.
+ *           v_mean: NULL, or [B,H,D] fp32 out => smooth_v: the per-channel mean (sum / ceil16(L), as
+ *           fused.cu:335,381 computes it) is subtracted before quantising and returned for the
+ *           attention epilogue.  ws: sage_stats_ws_floats(B,H,L,D) floats of scratch.
+ *           scale_max = 448 (e4m3 max).
+ */
+SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *v_mean, float *ws,
                     int B, int H, int L, int D,
                     int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     float scale_max, int dtype, void *stream);
 
 /* V pre-pass, FP16: (bf16 -> fp16) + transpose into the tile image.  Replaces `v.to(float16)`
- * (core.py:297-298,613).  Dense. */
-SAGE_API int sage_prep_v_f16(const void *v, void *v_image, int B, int H, int L, int D,
+ * (core.py:297-298,613) and, with v_mean != NULL ([B,H,D] fp32 to subtract), sub_mean_cuda
+ * (csrc/fused/fused.h, quant.py:182-222).  Dense. */
+SAGE_API int sage_prep_v_f16(const void *v, void *v_image, const float *v_mean, int B, int H, int L, int D,
                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int dtype, void *stream);
 
 /* Same for packed v[sum L, H, D]; cu_tiles = prefix sums of ceil(L_i/64); the image holds

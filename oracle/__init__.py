@@ -117,18 +117,28 @@ def quant_int8(x: np.ndarray, dtype: int, group: np.ndarray, ngroups: int, pre_s
     return out, scale
 
 
-def quant_v_fp8(v: np.ndarray, dtype: int, scale_max: float = 448.0):
-    """v [B,H,L,D] uint16 bits -> (e4m3 bytes [B,H,L,D] logical layout, v_scale [B,H,D])."""
+def quant_v_fp8(v: np.ndarray, dtype: int, scale_max: float = 448.0, mean: Optional[np.ndarray] = None):
+    """v [B,H,L,D] uint16 bits -> (e4m3 bytes [B,H,L,D] logical layout, v_scale [B,H,D]).
+    mean (fp32 [B,H,D], optional) = smooth_v: subtracted before quantising."""
     B, H, L, D = v.shape
     out = np.empty((B, H, L, D), dtype=np.uint8)
     vs = np.empty((B, H, D), dtype=np.float32)
-    rc = lib().orc_quant_v_fp8(_p(v), int(dtype), _p(out), _p(vs), int(B), int(H), int(L), int(D), ctypes.c_float(float(scale_max)))
+    if mean is not None:
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+    rc = lib().orc_quant_v_fp8(_p(v), int(dtype), _p(out), _p(vs), _p(mean), int(B), int(H), int(L), int(D),
+                               ctypes.c_float(float(scale_max)))
     assert rc == 0
     return out, vs
 
 
+def v_mean_padded16(v: np.ndarray, dtype: int) -> np.ndarray:
+    """The reference's smooth_v mean: sum over tokens / ceil16(L) in fp32 (fused.cu:335,381)."""
+    L = v.shape[2]
+    return (to_f32(v, dtype).astype(np.float64).sum(axis=2) / float((L + 15) // 16 * 16)).astype(np.float32)
+
+
 def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float, pv_mode: int,
-         out_dtype: int, v_scale=None, return_lse: bool = False):
+         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False):
     """Fused attention on quantised operands; returns (o bits uint16 [B,Hq,Lq,D], lse|None)."""
     B, Hq, Lq, D = q8.shape
     _, Hkv, Lk, _ = k8.shape
@@ -139,6 +149,7 @@ def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float,
     rc = lib().orc_attn(_p(q8), _p(k8), _p(v), _p(o), _p(lse),
                         _p(q_scale), _p(q_sidx), int(q_scale.shape[-1]),
                         _p(k_scale), _p(k_sidx), int(k_scale.shape[-1]), _p(v_scale),
+                        _p(None if v_mean is None else np.ascontiguousarray(v_mean, dtype=np.float32)),
                         int(B), int(Hq), int(Hkv), int(Lq), int(Lk), int(D), int(causal),
                         ctypes.c_float(float(c)), int(pv_mode), int(out_dtype))
     assert rc == 0, "orc_attn rejected the arguments"
@@ -167,7 +178,8 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
-                   qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32):
+                   qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32,
+                   smooth_v=False, vm=None):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -213,14 +225,23 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
         raise ValueError(qk_quant_gran)
     aux = dict(q8=q8, qs=qs, k8=k8, ks=ks, km=km, gq=gq, gk=gk, c=c)
     if pv == "f8":
-        v8, vs = quant_v_fp8(v, dtype)
-        aux.update(v8=v8, vs=vs)
+        # smooth_v (pv_accum_dtype="fp32" only, core.py:797-803): mean subtracted before quantising,
+        # added back in the epilogue; vm may be handed in (fp32 [B,Hkv,D]) so checker and kernel share it
+        if smooth_v and vm is None:
+            vm = v_mean_padded16(v, dtype)
+        v8, vs = quant_v_fp8(v, dtype, mean=vm if smooth_v else None)
+        aux.update(v8=v8, vs=vs, vm=vm)
         o, lse = attn(q8, k8, v8, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=PV_F8_TWO_LEVEL,
-                      out_dtype=dtype, v_scale=vs, return_lse=return_lse)
+                      out_dtype=dtype, v_scale=vs, v_mean=vm if smooth_v else None, return_lse=return_lse)
     else:
         mode = PV_F16_TRITON if pv == "f16_triton" else PV_F16_F32ACC
+        if smooth_v:   # sub_mean (quant.py:182-222): vm = v.mean(seq) in the input dtype, (v - vm) -> fp16
+            if vm is None:
+                vm = to_f32(k_mean(v, dtype), dtype)
+            vh = convert(to_f32(v, dtype) - vm[:, :, None, :], "f16")
+            aux.update(vm=vm)
         o, lse = attn(q8, k8, vh, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=mode,
-                      out_dtype=dtype, return_lse=return_lse)
+                      out_dtype=dtype, v_mean=vm if smooth_v else None, return_lse=return_lse)
     o = np.ascontiguousarray(o[..., :D0])
     if return_lse:
         lse = lse / np.float32(LOG2E)

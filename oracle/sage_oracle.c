@@ -213,27 +213,33 @@ ORC_EXPORT int orc_quant_int8(const uint16_t *x, int dtype, const uint16_t *mean
  * just as the gfx950 tiled layout is private to the HIP kernels.
  * amax==0 gives scale 0 and zeros here (reference: inf/NaN).
  */
-ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float *v_scale,
+ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float *v_scale, const float *mean,
                                int B, int H, int L, int D, float scale_max)
 {
+    /* mean (nullable, [B,H,D]): smooth_v -- subtracted before scaling; amax becomes
+     * max(|max - mean|, |min - mean|) (fused.cu:383-385).  The reference computes the mean itself as
+     * sum / ceil16(L) (fused.cu:335,381); it is an input here so that the checker and the checked
+     * kernel quantise against the very same mean. */
     for (int b = 0; b < B; b++)
         for (int h = 0; h < H; h++) {
             const uint16_t *vb = v + ((size_t)(b * H + h) * L) * D;
             uint8_t *ob = out + ((size_t)(b * H + h) * L) * D;
             float *sb = v_scale + (size_t)(b * H + h) * D;
             for (int d = 0; d < D; d++) {
-                float mx = -1000000.0f, mn = 1000000.0f;
+                const float mu = mean ? mean[(size_t)(b * H + h) * D + d] : 0.0f;
+                float mx = -INFINITY, mn = INFINITY;
                 for (int l = 0; l < L; l++) {
                     float f = ld16(vb + (size_t)l * D + d, dtype);
                     mx = fmaxf(mx, f);
                     mn = fminf(mn, f);
                 }
-                float amax = fmaxf(fabsf(mx), fabsf(mn));
+                float amax = fmaxf(fabsf(mx - mu), fabsf(mn - mu));
                 sb[d] = amax / scale_max;
                 float recp = amax > 0.0f ? scale_max / amax : 0.0f;
                 for (int l = 0; l < L; l++) {
-                    float f = ld16(vb + (size_t)l * D + d, dtype) * recp;
-                    ob[(size_t)l * D + d] = orc_f2e4m3(f);
+                    float f = ld16(vb + (size_t)l * D + d, dtype);
+                    if (mean) f -= mu;
+                    ob[(size_t)l * D + d] = orc_f2e4m3(f * recp);
                 }
             }
         }
@@ -248,7 +254,8 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  * v  pv_mode 0/1: [B,Hkv,Lk,D] fp16 bits; pv_mode 2/3: [B,Hkv,Lk,D] e4m3 bytes
  * q_scale [B,Hq,nqs], q_sidx[Lq]: scale slot of each query row
  * k_scale [B,Hkv,nks], k_sidx[Lk]: scale slot of each key
- * v_scale [B,Hkv,D] (fp8 modes) or NULL
+ * v_scale [B,Hkv,D] (fp8 modes) or NULL; v_mean [B,Hkv,D] or NULL: added after normalisation
+ *   (smooth_v: epilogue order normalise -> x v_scale -> + v_mean, qk_int_sv_f8_cuda_sm89.cuh:572-656)
  * c: multiplier applied to the dequantised score; 1.0 when sm_scale*log2e was
  *    folded into Q (quant_per_block.py:87), sm_scale*log2e otherwise
  *    (qk_int_sv_f8_cuda_sm89.cuh:298,334-335).
@@ -276,7 +283,7 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
 ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_t *o, float *lse,
                         const float *q_scale, const int32_t *q_sidx, int nqs,
                         const float *k_scale, const int32_t *k_sidx, int nks,
-                        const float *v_scale,
+                        const float *v_scale, const float *v_mean,
                         int B, int Hq, int Hkv, int Lq, int Lk, int D,
                         int causal, float c, int pv_mode, int out_dtype)
 {
@@ -368,6 +375,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                     for (int d = 0; d < D; d++) {
                         float x = acc[i][d] / l[i];
                         if (fp8) x *= v_scale[(size_t)(b * Hkv + hk) * D + d];
+                        if (v_mean) x += v_mean[(size_t)(b * Hkv + hk) * D + d];   /* sm89.cuh:575-621 */
                         orow[d] = st16(x, out_dtype);
                     }
                     if (lse) lse[(size_t)(b * Hq + h) * Lq + r0 + i] = log2f(l[i]) + m[i];

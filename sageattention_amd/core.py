@@ -6,8 +6,8 @@ Same six public names, same signatures, same kwargs and error behaviour as the r
 ``sageattn_qk_int8_pv_fp8_cuda`` :636, ``sageattn_qk_int8_pv_fp8_cuda_sm90`` :829), so
 ``F.scaled_dot_product_attention = sageattn`` in the CogVideoX / Hunyuan / Wan examples keeps
 working.  Host code here is plumbing only (padding, K mean, allocation, LSE fix-up -- exactly
-what the reference does in Python); every tensor-sized computation except ``k.mean`` runs in
-the hand-written HIP kernels behind ``libsage_gfx950.so``.  There is no fallback path: CPU
+what the reference does in Python); every tensor-sized computation, including the K-smoothing
+mean, runs in the hand-written HIP kernels behind ``libsage_gfx950.so``.  There is no fallback path: CPU
 tensors or a missing library raise.
 """
 from __future__ import annotations
@@ -19,8 +19,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _cabi
-from .quant import (LOG2E, _dims, _p, _stream, per_block_int8, per_block_int8_varlen, per_channel_fp8,
-                    per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen)
+from .quant import (LOG2E, _dims, _p, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
+                    per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, sub_mean)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
 
@@ -50,26 +50,27 @@ def _pad_head_dim(q, k, v):
     return q, k, v, head_dim_og
 
 
-def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
-    """core.py:279-295: km = mean of k over the sequence, and q.km^T for the LSE fix-up."""
-    seq_dim = 1 if tensor_layout == "NHD" else 2
+def _lse_correction(q, km, tensor_layout):
+    """core.py:283-293: q . km^T per query row (fp32), km broadcast over the GQA group."""
     nh_dim = 2 if tensor_layout == "NHD" else 1
+    g = q.size(nh_dim) // km.size(nh_dim)
+    km_b = torch.repeat_interleave(km, g, dim=nh_dim) if g > 1 else km
+    if tensor_layout == "NHD":
+        return torch.matmul(q.transpose(1, 2), km_b.transpose(1, 2).transpose(2, 3)).squeeze(-1).to(torch.float32)
+    return torch.matmul(q, km_b.transpose(2, 3)).squeeze(-1).to(torch.float32)
+
+
+def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
+    """core.py:279-295: km = mean of k over the sequence (keepdim), and q.km^T for the LSE fix-up."""
     if not smooth_k:
         return None, None
-    km = k.mean(dim=seq_dim, keepdim=True)
-    lse_correction = None
-    if return_lse:
-        g = q.size(nh_dim) // k.size(nh_dim)
-        km_b = torch.repeat_interleave(km, g, dim=nh_dim) if g > 1 else km
-        if tensor_layout == "NHD":
-            lse_correction = torch.matmul(q.transpose(1, 2), km_b.transpose(1, 2).transpose(2, 3)).squeeze(-1).to(torch.float32)
-        else:
-            lse_correction = torch.matmul(q, km_b.transpose(2, 3)).squeeze(-1).to(torch.float32)
-    return km, lse_correction
+    seq_dim = 1 if tensor_layout == "NHD" else 2
+    km = channel_mean(k, tensor_layout).unsqueeze(seq_dim)     # k.mean(dim=seq_dim, keepdim=True) as a HIP reduction
+    return km, (_lse_correction(q, km, tensor_layout) if return_lse else None)
 
 
 def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dtype, tensor_layout, is_causal,
-                gran, q_warp, sm_scale_log2, two_level, return_lse):
+                gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None):
     """Allocate ``o`` (+ ``lse``) and launch the fused kernel through the C ABI."""
     B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q_int8, tensor_layout)
     _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
@@ -82,13 +83,13 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     lib = _cabi.load()
     if fp8:
         rc = lib.sage_attn_qk_int8_pv_f8(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
-                                         _p(v_scale), None, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                                         _p(v_scale), _p(v_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
                                          o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
                                          _stream(o))
         _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
     else:
         rc = lib.sage_attn_qk_int8_pv_f16(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
-                                          None, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                                          _p(v_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
                                           o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
                                           _stream(o))
         _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
@@ -158,7 +159,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     assert cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous(), "cu_seqlens_q and cu_seqlens_k must be contiguous."
     Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[2]
     assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
-    km = k.mean(dim=0, keepdim=True) if smooth_k else None   # over ALL packed tokens, as core.py:432-434
+    km = channel_mean_packed(k) if smooth_k else None   # mean over ALL packed tokens, as core.py:432-434
     if sm_scale is None:
         sm_scale = 1.0 / (head_dim_og ** 0.5)
     q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
@@ -207,13 +208,19 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     if sm_scale is None:
         sm_scale = head_dim_og ** -0.5
     km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-    if smooth_v:
-        warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")   # FP32 accumulators on gfx950
+    if pv_accum_dtype in ["fp32", "fp16+fp32"] and smooth_v:
+        warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")   # core.py:608-610
+        smooth_v = False
     warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32" and qk_quant_gran == "per_warp") else 32
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale)
-    v_image = prep_v_fp16(v, tensor_layout)
+    vm = None
+    if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
+        v_image, vm = sub_mean(v, tensor_layout)
+        vm = vm.float()
+    else:
+        v_image = prep_v_fp16(v, tensor_layout)
     o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, pv_accum_dtype == "fp16+fp32", return_lse)
+                         gran, q_warp, sm_log2, pv_accum_dtype == "fp16+fp32", return_lse, v_mean=vm)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
@@ -236,12 +243,13 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     if sm_scale is None:
         sm_scale = head_dim_og ** -0.5
     km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-    if smooth_v:
-        warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")
+    if pv_accum_dtype in ("fp32+fp32", "fp32+fp16") and smooth_v:
+        warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")   # core.py:797-803
+        smooth_v = False
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)
-    v_image, v_scale, _ = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=False)
+    v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse)
+                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 

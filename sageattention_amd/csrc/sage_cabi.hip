@@ -156,8 +156,24 @@ SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *
     return check_launch(sage::launch_quant_int8(p, static_cast<hipStream_t>(stream)), "sage_quant_qk_int8_varlen launch");
 }
 
-static int prep_v_common(const void *v, void *v_image, float *v_scale, float *amax_ws, const int32_t *cu,
-                         const int32_t *cu_tiles, int B, int H, int L, int D,
+static int stats_common(const void *x, void *mean_out, float *ws, float *stats, int B, int H, int L, int D,
+                        int64_t x_sb, int64_t x_sh, int64_t x_sl, int dtype, void *stream, const char *what)
+{
+    SAGE_REQUIRE(x && ws, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(aligned16(x), "input must be 16-byte aligned");
+    SAGE_REQUIRE(x_sl % 8 == 0 && x_sh % 8 == 0 && x_sb % 8 == 0, "strides must be multiples of 8 elements");
+    sage::StatsParams p{};
+    p.x = x; p.ws = ws; p.stats = stats; p.mean_out = mean_out;
+    p.B = B; p.H = H; p.L = L; p.D = D; p.nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+    p.x_sb = x_sb; p.x_sh = x_sh; p.x_sl = x_sl; p.dtype = dtype;
+    return check_launch(sage::launch_stats(p, static_cast<hipStream_t>(stream)), what);
+}
+
+static int prep_v_common(const void *v, void *v_image, float *v_scale, float *v_mean_out, const float *v_mean_in,
+                         const float *stats, const int32_t *cu, const int32_t *cu_tiles, int B, int H, int L, int D,
                          int64_t v_sb, int64_t v_sh, int64_t v_sl, float scale_max, int dtype, int fp8, void *stream)
 {
     SAGE_REQUIRE(v && v_image, "null tensor pointer");
@@ -167,39 +183,53 @@ static int prep_v_common(const void *v, void *v_image, float *v_scale, float *am
     SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
     SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "v strides must be multiples of 8 elements");
     sage::PrepVParams p{};
-    p.v = v; p.out = v_image; p.amax = amax_ws; p.v_scale = v_scale; p.cu = cu; p.cu_tiles = cu_tiles;
+    p.v = v; p.out = v_image; p.stats = stats; p.mean_in = v_mean_in; p.v_scale = v_scale; p.v_mean = v_mean_out;
+    p.cu = cu; p.cu_tiles = cu_tiles;
     p.B = B; p.H = H; p.L = L; p.D = D; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
     p.dtype = dtype; p.fp8 = fp8; p.scale_max = scale_max;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (fp8) {
-        SAGE_REQUIRE(v_scale && amax_ws, "fp8 V pre-pass needs v_scale and amax workspace");
-        SAGE_REQUIRE(scale_max > 0.0f, "scale_max must be positive");
-        hipError_t e = hipMemsetAsync(amax_ws, 0, sizeof(float) * (size_t)B * H * D, s);
-        if (e != hipSuccess) return check_launch(e, "amax workspace memset");
-        int rc = check_launch(sage::launch_v_absmax(p, s), "sage_v_absmax launch");
-        if (rc != SAGE_OK) return rc;
-    }
-    return check_launch(sage::launch_prep_v(p, s), "sage_prep_v launch");
+    return check_launch(sage::launch_prep_v(p, static_cast<hipStream_t>(stream)), "sage_prep_v launch");
 }
 
-SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *amax_ws,
+SAGE_API int64_t sage_stats_ws_floats(int B, int H, int L, int D)
+{
+    const int64_t nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+    return (int64_t)B * H * (nslab + 1) * 3 * D;
+}
+
+SAGE_API int sage_channel_mean(const void *x, void *mean_out, float *ws, int B, int H, int L, int D,
+                               int64_t x_sb, int64_t x_sh, int64_t x_sl, int dtype, void *stream)
+{
+    SAGE_REQUIRE(mean_out, "null output pointer");
+    return stats_common(x, mean_out, ws, nullptr, B, H, L, D, x_sb, x_sh, x_sl, dtype, stream, "sage_channel_mean launch");
+}
+
+SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *v_mean, float *ws,
                     int B, int H, int L, int D, int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     float scale_max, int dtype, void *stream)
 {
-    return prep_v_common(v, v_image, v_scale, amax_ws, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl, scale_max, dtype, 1, stream);
+    SAGE_REQUIRE(v_scale && ws, "fp8 V pre-pass needs v_scale and the statistics workspace");
+    SAGE_REQUIRE(scale_max > 0.0f, "scale_max must be positive");
+    const int64_t nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+    float *stats = ws + (int64_t)B * H * nslab * 3 * D;      // final block lives behind the partials
+    int rc = stats_common(v, nullptr, ws, stats, B, H, L, D, v_sb, v_sh, v_sl, dtype, stream, "sage_v_stats launch");
+    if (rc != SAGE_OK) return rc;
+    return prep_v_common(v, v_image, v_scale, v_mean, nullptr, stats, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl,
+                         scale_max, dtype, 1, stream);
 }
 
-SAGE_API int sage_prep_v_f16(const void *v, void *v_image, int B, int H, int L, int D,
+SAGE_API int sage_prep_v_f16(const void *v, void *v_image, const float *v_mean, int B, int H, int L, int D,
                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int dtype, void *stream)
 {
-    return prep_v_common(v, v_image, nullptr, nullptr, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl, 0.0f, dtype, 0, stream);
+    return prep_v_common(v, v_image, nullptr, nullptr, v_mean, nullptr, nullptr, nullptr, B, H, L, D, v_sb, v_sh, v_sl,
+                         0.0f, dtype, 0, stream);
 }
 
 SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t *cu_seqlens, const int32_t *cu_tiles,
                            int nseq, int max_seqlen, int H, int D, int64_t v_sl, int64_t v_sh, int dtype, void *stream)
 {
     SAGE_REQUIRE(cu_seqlens && cu_tiles, "varlen needs cu_seqlens and cu_tiles");
-    return prep_v_common(v, v_image, nullptr, nullptr, cu_seqlens, cu_tiles, nseq, H, max_seqlen, D, 0, v_sh, v_sl, 0.0f, dtype, 0, stream);
+    return prep_v_common(v, v_image, nullptr, nullptr, nullptr, nullptr, cu_seqlens, cu_tiles, nseq, H, max_seqlen, D, 0, v_sh, v_sl,
+                         0.0f, dtype, 0, stream);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,

@@ -62,12 +62,27 @@ struct QuantParams {
 };
 hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream);
 
+// ---- per-channel statistics over the sequence (K mean, V amax / mean) -----------------------------
+constexpr int kStatsSlab = 512;   // tokens per stage-1 workgroup
+struct StatsParams {
+    const void *x;            // fp16 / bf16 [.., L, D] with strides
+    float *ws;                // [B,H,nslab,3,D] partial (max, min, sum)
+    float *stats;             // nullable [B,H,3,D] final (max, min, sum)
+    void *mean_out;           // nullable [B,H,D] mean in the input dtype
+    int B, H, L, D, nslab;
+    long x_sb, x_sh, x_sl;
+    int dtype;
+};
+hipError_t launch_stats(const StatsParams &p, hipStream_t stream);
+
 // ---- V pre-pass -------------------------------------------------------------------------------
 struct PrepVParams {
     const void *v;            // fp16 / bf16 [.., L, D] with strides
     void *out;                // tiled V^T image, fp8 or fp16
-    float *amax;              // [B,H,D] workspace (fp8): per-channel abs max (as float)
+    const float *stats;       // fp8: [B,H,3,D] (max, min, sum) from launch_stats
+    const float *mean_in;     // fp16 path: nullable [B,H,D] mean to subtract (smooth_v)
     float *v_scale;           // [B,H,D] out (fp8)
+    float *v_mean;            // fp8: nullable [B,H,D] out; non-null = smooth_v (subtract the mean)
     const int32_t *cu;        // varlen
     const int32_t *cu_tiles;  // varlen: prefix of ceil(L_i/64)
     int B, H, L, D;
@@ -76,7 +91,6 @@ struct PrepVParams {
     int fp8;                  // 1: e4m3 output, 0: fp16 output
     float scale_max;
 };
-hipError_t launch_v_absmax(const PrepVParams &p, hipStream_t stream);
 hipError_t launch_prep_v(const PrepVParams &p, hipStream_t stream);
 
 }  // namespace sage

@@ -15,46 +15,12 @@
 // reads are conflict-free ds_read_b128.  Tokens >= L are zero (the reference zero-pads too,
 // fused.cu:283-286) so masked probabilities never multiply garbage.
 //
-// HBM traffic: absmax pass reads V once (2 B/elt); the quantise pass reads it again and writes
-// 1 B/elt (fp8) -- 5 B/elt against the reference's 9 B/elt (fp16 intermediate written + read twice).
+// HBM traffic: the statistics pass (sage_stats.hip) reads V once (2 B/elt); the quantise pass reads it
+// again and writes 1 B/elt (fp8) -- 5 B/elt against the reference's 9 B/elt (fp16 intermediate written + read twice).
 #include "sage_common.h"
 #include "sage_kernels.h"
 
 namespace sage {
-
-constexpr int kSlab = 256;   // tokens per absmax workgroup
-
-template <int D, int DT>
-__global__ void __launch_bounds__(256)
-v_absmax_kernel(const PrepVParams p)
-{
-    __shared__ unsigned cmax[D];
-    constexpr int TPR = D / 8;           // threads per row (16 B each)
-    constexpr int RPI = 256 / TPR;       // rows per iteration
-    const int tid = threadIdx.x;
-    const int slab = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    if (tid < D) cmax[tid] = 0u;
-    __syncthreads();
-    const uint16_t *v = reinterpret_cast<const uint16_t *>(p.v) + (long)b * p.v_sb + (long)h * p.v_sh;
-    const int c8 = (tid % TPR) * 8;
-    float mx[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) mx[j] = 0.0f;
-    const int end = min(p.L, slab * kSlab + kSlab);
-    for (int r = slab * kSlab + tid / TPR; r < end; r += RPI) {
-        const v4u raw = *reinterpret_cast<const v4u *>(v + (long)r * p.v_sl + c8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const unsigned w = raw[j >> 1];
-            mx[j] = fmaxf(mx[j], fabsf(ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)))));
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) atomicMax(&cmax[c8 + j], __float_as_uint(mx[j]));
-    __syncthreads();
-    if (tid < D)
-        atomicMax(reinterpret_cast<unsigned *>(p.amax) + ((long)b * p.H + h) * D + tid, cmax[tid]);
-}
 
 template <int D, int DT, bool FP8>
 __global__ void __launch_bounds__(256)
@@ -91,21 +57,39 @@ prep_v_kernel(const PrepVParams p)
     __syncthreads();
 
     if constexpr (FP8) {
-        const float *amax = p.amax + ((long)b * p.H + h) * D;
-        if (t == 0 && tid < D) p.v_scale[((long)b * p.H + h) * D + tid] = amax[tid] / p.scale_max;
+        // per-channel scale (and mean for smooth_v) from the (max, min, sum) statistics:
+        //   plain   : amax = max(|max|, |min|)                              (fused.cu:388)
+        //   smooth_v: mean = sum / ceil16(L)  (the reference divides by the 16-padded length,
+        //             fused.cu:335,381), amax = max(|max - mean|, |min - mean|)  (fused.cu:383-385)
+        const float *st = p.stats + ((long)b * p.H + h) * 3 * D;
+        const bool smooth = p.v_mean != nullptr;
+        const float lpad = (float)((L + 15) / 16 * 16);
+        auto chan = [&](int d, float &mean, float &am) {
+            mean = smooth ? st[2 * D + d] / lpad : 0.0f;
+            am = fmaxf(fabsf(st[d] - mean), fabsf(st[D + d] - mean));
+        };
+        if (t == 0 && tid < D) {
+            float mean, am;
+            chan(tid, mean, am);
+            p.v_scale[((long)b * p.H + h) * D + tid] = am / p.scale_max;
+            if (smooth) p.v_mean[((long)b * p.H + h) * D + tid] = mean;
+        }
         unsigned char *out = reinterpret_cast<unsigned char *>(p.out) + tile_idx * (long)(D * 64);
 #pragma unroll
         for (int i = 0; i < D * 4 / 256; i++) {
             const int piece = tid + 256 * i;
             const int d = piece >> 2, pc = piece & 3;
             const int ch = swz_chunk<64>(d, pc);                   // involution: physical <-> logical
-            const float am = amax[d];
+            float mean, am;
+            chan(d, mean, am);
             const float recp = am > 0.0f ? p.scale_max / am : 0.0f;   // fused.cu:395
             float f[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int tok = pv_token_of_position(16 * ch + j);
-                float x = ld16<DT>(tile[tok * LDT + d]) * recp;
+                float x = ld16<DT>(tile[tok * LDT + d]);
+                if (smooth) x = (t * BLKK + tok < L) ? x - mean : 0.0f;   // padding stays zero
+                x *= recp;
                 f[j] = fminf(fmaxf(x, -448.0f), 448.0f);             // satfinite
             }
             v4u pk;
@@ -132,7 +116,10 @@ prep_v_kernel(const PrepVParams p)
                 for (int e = 0; e < 2; e++) {
                     const int tok = pv_token_of_position(8 * ch + 2 * w + e);
                     uint16_t raw = tile[tok * LDT + d];
-                    if (DT != DT_F16) raw = f32_to_f16_rne(bf16_to_f32(raw));   // v.to(float16)
+                    if (p.mean_in != nullptr) {   // sub_mean (quant.py:182-222, fused.cu:200-260): (v - vm) -> fp16
+                        const float m = p.mean_in[((long)b * p.H + h) * D + d];
+                        raw = (t * BLKK + tok < L) ? f32_to_f16_rne(ld16<DT>(raw) - m) : (uint16_t)0;
+                    } else if (DT != DT_F16) raw = f32_to_f16_rne(bf16_to_f32(raw));   // v.to(float16)
                     word |= (unsigned)raw << (16 * e);
                 }
                 pk[w] = word;
@@ -140,19 +127,6 @@ prep_v_kernel(const PrepVParams p)
             *reinterpret_cast<v4u *>(out + d * 128 + pc * 16) = pk;
         }
     }
-}
-
-hipError_t launch_v_absmax(const PrepVParams &p, hipStream_t s)
-{
-    const int nslab = (p.L + kSlab - 1) / kSlab;
-    if (nslab <= 0 || p.B <= 0) return hipSuccess;
-    dim3 grid(nslab, p.H, p.B);
-#define SAGE_AM(D_, T_) hipLaunchKernelGGL((v_absmax_kernel<D_, T_>), grid, dim3(256), 0, s, p)
-    if (p.D == 128) { if (p.dtype == DT_F16) SAGE_AM(128, DT_F16); else SAGE_AM(128, DT_BF16); }
-    else if (p.D == 64) { if (p.dtype == DT_F16) SAGE_AM(64, DT_F16); else SAGE_AM(64, DT_BF16); }
-    else return hipErrorInvalidValue;
-#undef SAGE_AM
-    return hipGetLastError();
 }
 
 hipError_t launch_prep_v(const PrepVParams &p, hipStream_t s)

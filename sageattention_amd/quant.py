@@ -155,35 +155,72 @@ def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_se
     return q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks
 
 
+def _stats_ws(B: int, H: int, L: int, D: int, device) -> torch.Tensor:
+    return torch.empty((int(_cabi.load().sage_stats_ws_floats(B, H, L, D)),), dtype=torch.float32, device=device)
+
+
+def channel_mean(x: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
+    """``x.mean(dim=seq)`` in the input dtype, shape ``[B, H, D]`` -- the K-smoothing mean
+    (core.py:280) and the V mean of ``sub_mean`` (quant.py:216) as one deterministic HIP reduction
+    (fp32 accumulation, one rounding) instead of a torch op."""
+    x = _aligned(x, 8)
+    B, H, L, D, sb, sh, sl = _dims(x, tensor_layout)
+    out = torch.empty((B, H, D), dtype=x.dtype, device=x.device)
+    ws = _stats_ws(B, H, L, D, x.device)
+    rc = _cabi.load().sage_channel_mean(_p(x), _p(out), _p(ws), B, H, L, D, sb, sh, sl, _dtype_code(x), _stream(x))
+    _cabi.check(rc, "sage_channel_mean")
+    return out
+
+
+def channel_mean_packed(x: torch.Tensor) -> torch.Tensor:
+    """Mean over ALL tokens of a packed ``[sum L, H, D]`` tensor -> ``[1, H, D]`` (core.py:432-434)."""
+    x = _aligned(x, 8)
+    T, H, D = x.shape
+    out = torch.empty((1, H, D), dtype=x.dtype, device=x.device)
+    ws = _stats_ws(1, H, T, D, x.device)
+    rc = _cabi.load().sage_channel_mean(_p(x), _p(out), _p(ws), 1, H, T, D, 0, x.stride(1), x.stride(0), _dtype_code(x), _stream(x))
+    _cabi.check(rc, "sage_channel_mean")
+    return out
+
+
 def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = False
                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Per-channel FP8 (e4m3fn) quantisation of V fused with the transpose into the PV tile image
     (reference: quant.py:224-293).  Returns ``(v_image uint8 [B,H,ceil(L/64),D,64],
-    v_scale fp32 [B,H,D], None)``.  ``smooth_v`` is not implemented on gfx950 (FP32 accumulators
-    make it unnecessary); passing True raises."""
-    if smooth_v:
-        raise NotImplementedError("smooth_v is not implemented in the gfx950 V pre-pass")
+    v_scale fp32 [B,H,D], vm)`` where ``vm`` is the fp32 per-channel mean ``[B,H,D]`` that was
+    subtracted when ``smooth_v`` (to be added back by the attention epilogue), else None."""
     v = _aligned(v, 8)
     B, H, L, D, sb, sh, sl = _dims(v, tensor_layout)
     nt = (L + 63) // 64
     v_image = torch.empty((B, H, nt, D, 64), dtype=torch.uint8, device=v.device)
     v_scale = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
-    amax_ws = torch.empty((B, H, D), dtype=torch.float32, device=v.device)
-    rc = _cabi.load().sage_prep_v_fp8(_p(v), _p(v_image), _p(v_scale), _p(amax_ws), B, H, L, D, sb, sh, sl,
+    vm = torch.empty((B, H, D), dtype=torch.float32, device=v.device) if smooth_v else None
+    ws = _stats_ws(B, H, L, D, v.device)
+    rc = _cabi.load().sage_prep_v_fp8(_p(v), _p(v_image), _p(v_scale), _p(vm), _p(ws), B, H, L, D, sb, sh, sl,
                                       float(scale_max), _dtype_code(v), _stream(v))
     _cabi.check(rc, "sage_prep_v_fp8")
-    return v_image, v_scale, None
+    return v_image, v_scale, vm
 
 
-def prep_v_fp16(v: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
-    """FP16-PV paths: ``v.to(float16)`` (core.py:297-298,613) fused with the transpose into the
-    tile image ``[B,H,ceil(L/64),D,64]`` (fp16)."""
+def prep_v_fp16(v: torch.Tensor, tensor_layout: str = "HND", vm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FP16-PV paths: ``v.to(float16)`` (core.py:297-298,613) -- or ``(v - vm).to(float16)`` when a
+    per-channel mean ``vm`` fp32 ``[B,H,D]`` is given (``sub_mean``) -- fused with the transpose into
+    the tile image ``[B,H,ceil(L/64),D,64]`` (fp16)."""
     v = _aligned(v, 8)
     B, H, L, D, sb, sh, sl = _dims(v, tensor_layout)
     v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.float16, device=v.device)
-    rc = _cabi.load().sage_prep_v_f16(_p(v), _p(v_image), B, H, L, D, sb, sh, sl, _dtype_code(v), _stream(v))
+    if vm is not None:
+        assert vm.dtype == torch.float32 and vm.shape == (B, H, D) and vm.is_contiguous()
+    rc = _cabi.load().sage_prep_v_f16(_p(v), _p(v_image), _p(vm), B, H, L, D, sb, sh, sl, _dtype_code(v), _stream(v))
     _cabi.check(rc, "sage_prep_v_f16")
     return v_image
+
+
+def sub_mean(v: torch.Tensor, tensor_layout: str = "HND"):
+    """Reference ``sub_mean`` (quant.py:182-222): returns ``(smoothed V as fp16 tile image, vm [B,H,D] in
+    the dtype of v)``; the mean is added back in the attention epilogue."""
+    vm = channel_mean(v, tensor_layout)
+    return prep_v_fp16(v, tensor_layout, vm=vm.float()), vm
 
 
 def prep_v_fp16_varlen(v: torch.Tensor, cu_seqlens_k: torch.Tensor, cu_tiles: torch.Tensor, max_seqlen_k: int) -> torch.Tensor:

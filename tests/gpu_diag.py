@@ -30,7 +30,7 @@ def run(tag, B, Hq, Hkv, Lq, Lk, D, dt, causal):
     k = (torch.randn(B, Hkv, Lk, D, generator=g) + 1.0).to(tt)
     v = torch.randn(B, Hkv, Lk, D, generator=g).to(tt)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
-    km = kd.mean(dim=2, keepdim=True)
+    km = sq.channel_mean(kd).unsqueeze(2)
     save = dict(q=util.bits(q), k=util.bits(k), v=util.bits(v), km=util.bits(km))
     for gran in ("per_block", "per_warp", "per_thread"):
         for pv in ("f8", "f16"):

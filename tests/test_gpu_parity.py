@@ -40,6 +40,13 @@ def _gpu_and_report():
         json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
+def oracle_km_packed(k_bits, dt):
+    """k.mean(dim=0, keepdim=True) of a packed [T,H,D] tensor in the input dtype (core.py:433), on the host."""
+    import oracle
+    kf = oracle.to_f32(k_bits, dt)
+    return oracle.convert(kf.astype(np.float64).mean(axis=0, keepdims=True).astype(np.float32), "f16" if dt == 0 else "bf16")
+
+
 def T(dtype_code):
     return torch.float16 if dtype_code == 0 else torch.bfloat16
 
@@ -129,6 +136,70 @@ def test_prep_v_images_bit_exact(oracle_mod, dt, D, layout, L):
     assert (got16 == r16).all()
 
 
+@pytest.mark.parametrize("dt,D,layout,L", [(0, 128, "HND", 1500), (1, 64, "NHD", 513), (1, 128, "NHD", 64), (0, 64, "HND", 7)])
+def test_channel_mean_matches_torch_and_is_deterministic(dt, D, layout, L):
+    """K-smoothing mean as a HIP reduction (replaces torch's k.mean, core.py:280): fp32 accumulate, one rounding."""
+    g = torch.Generator().manual_seed(8)
+    k = (torch.randn(2, 3, L, D, generator=g) + 2.0 * torch.randn(1, 3, 1, D, generator=g)).to(T(dt))
+    kd = to_dev(k, layout)
+    a = sq.channel_mean(kd, layout)
+    b = sq.channel_mean(kd, layout)
+    torch.cuda.synchronize()
+    assert a.shape == (2, 3, D) and a.dtype == k.dtype and torch.equal(a, b)
+    want = k.double().mean(dim=2)
+    ulp = (2.0 ** -10 if dt == 0 else 2.0 ** -7) * want.abs().clamp_min(2.0 ** -14)
+    assert ((a.cpu().double() - want).abs() <= 0.51 * ulp + 1e-7).all()      # correctly rounded up to fp32 summation error
+    # packed [sum L, H, D] form used by sageattn_varlen
+    kp = kd if layout == "NHD" else kd.transpose(1, 2).contiguous()
+    m = sq.channel_mean_packed(kp.reshape(-1, 3, D))
+    want_p = k.double().mean(dim=(0, 2))
+    assert m.shape == (1, 3, D) and ((m[0].cpu().double() - want_p).abs() <= 0.51 * (2.0 ** -10 if dt == 0 else 2.0 ** -7) * want_p.abs().clamp_min(2.0 ** -14) + 1e-7).all()
+
+
+@pytest.mark.parametrize("dt,D,layout,L", [(0, 128, "HND", 300), (1, 64, "NHD", 129)])
+def test_prep_v_fp8_smooth_v_bit_exact(oracle_mod, dt, D, layout, L):
+    g = torch.Generator().manual_seed(6)
+    v = (torch.randn(2, 2, L, D, generator=g) + 4.0 * torch.randn(1, 2, 1, D, generator=g)).to(T(dt))
+    img8, vs, vm = sq.per_channel_fp8(to_dev(v, layout), tensor_layout=layout, smooth_v=True)
+    torch.cuda.synchronize()
+    vm_h = vm.cpu().numpy()
+    want_vm = oracle_mod.v_mean_padded16(util.bits(v), dt)                    # sum / ceil16(L), fused.cu:335,381
+    assert np.abs(vm_h - want_vm).max() <= 1e-5 * max(1.0, float(np.abs(want_vm).max()))
+    r8, rvs = oracle_mod.quant_v_fp8(util.bits(v), dt, mean=vm_h)            # same mean -> bit-exact bytes
+    assert (vs.cpu().numpy() == rvs).all()
+    got8 = util.decode_v_image(img8.cpu().numpy(), L, fp8=True)
+    assert (got8 == r8).all(), f"{(got8 != r8).sum()} fp8 mismatches"
+    full = util.decode_v_image(img8.cpu().numpy(), img8.shape[2] * 64, fp8=True)
+    assert (full[..., L:, :] == 0).all()                                       # padding stays zero, not -mean
+
+
+@pytest.mark.parametrize("pv", ["f8", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_smooth_v_paths_vs_oracle_and_sdpa(oracle_mod, pv, causal):
+    """smooth_v: reference core.py:617-619 (fp16 accumulate API) and :811-813 (fp8, pv_accum_dtype="fp32")."""
+    dt = 0
+    q, k, v = rand_qkv(1, 4, 2, 333, 333, 128, dt, seed=31, kbias=1.0)
+    v = (v.float() + 3.0 * torch.randn(1, 2, 1, 128, generator=torch.Generator().manual_seed(1))).half()
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    km = util.bits(sq.channel_mean(kd))
+    if pv == "f8":
+        o = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_warp", pv_accum_dtype="fp32", smooth_v=True)
+        vm = sq.per_channel_fp8(vd, smooth_v=True)[2].cpu().numpy()
+    else:
+        o = sa.sageattn_qk_int8_pv_fp16_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_warp", pv_accum_dtype="fp16", smooth_v=True)
+        vm = sq.channel_mean(vd).float().cpu().numpy()
+    torch.cuda.synchronize()
+    ref, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv=pv,
+                                          qk_quant_gran="per_warp", km=km, smooth_v=True, vm=vm)
+    got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-3 * scale + 2 ** -11 * scale
+    truth = util.sdpa_f32(q, k, v, causal).numpy()
+    rel = util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
+    REPORT[f"sdpa/smooth_v/{pv}/{'c' if causal else 'nc'}"] = dict(rel_rmse=rel, cos=util.cos_sim(got, truth))
+    assert rel <= (0.02 if pv == "f8" else 0.01)
+
+
 # ------------------------------------------------------------------------------------------------ attention kernel vs oracle
 CASES = [
     # name,                    B Hq Hkv  Lq   Lk   D   dt
@@ -151,7 +222,7 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=100 + [c[0] for c in CASES].index(name), kbias=1.5)
     fp8 = pv.startswith("f8")
     # the K mean is host plumbing (torch, as in the reference): hand the oracle the very same km
-    km = util.bits(k.to(DEV).mean(dim=2))
+    km = util.bits(sq.channel_mean(k.to(DEV)))
     o_bits, lse_ref, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal,
                                             pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km,
                                             warpq=16 if (pv == "f16_two" and D == 128) else 32)   # core.py:602
@@ -212,7 +283,7 @@ def test_varlen_vs_reference_golden(name):
     REPORT[f"golden/{name}"] = dict(max_abs=err, max_o=scale)
     assert err <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
     # bit-exact quantisation vs the reference's varlen quantiser (km subtraction fused in-kernel)
-    km = k.mean(dim=0, keepdim=True)
+    km = util.from_bits(oracle_km_packed(z["k"], dt), dt, DEV)              # the reference's torch mean, restated
     q8, qs, k8, ks, cu_qs, cu_ks = sq.per_block_int8_varlen(q, k, cu, cu, int(lens.max()), int(lens.max()), km=km, sm_scale=D ** -0.5)
     assert (cu_qs.cpu().numpy() == z["cu_qs"]).all() and (cu_ks.cpu().numpy() == z["cu_ks"]).all()
     assert (q8.cpu().numpy() == z["q_int8"]).all() and (qs.cpu().numpy() == z["q_scale"]).all()

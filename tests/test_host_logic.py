@@ -34,12 +34,15 @@ def test_pad_head_dim_rules():
         core._pad_head_dim(*(torch.zeros(1, 1, 4, 160, dtype=torch.float16),) * 3)
 
 
-def test_smooth_k_and_lse_correction_shapes():
+def test_lse_correction_shapes_and_values():
     q = torch.randn(2, 4, 10, 64).half(); k = torch.randn(2, 2, 12, 64).half()
-    km, corr = core._smooth_k(q, k, "HND", True, True)
-    assert km.shape == (2, 2, 1, 64) and corr.shape == (2, 4, 10) and corr.dtype == torch.float32
-    km, corr = core._smooth_k(q.transpose(1, 2), k.transpose(1, 2), "NHD", True, True)
-    assert km.shape == (2, 1, 2, 64) and corr.shape == (2, 4, 10)
+    km = k.mean(dim=2, keepdim=True)
+    corr = core._lse_correction(q, km, "HND")
+    assert corr.shape == (2, 4, 10) and corr.dtype == torch.float32
+    want = torch.einsum("bhld,bhd->bhl", q.float(), km[:, :, 0].float().repeat_interleave(2, 1))
+    assert (corr - want).abs().max() < 2e-2
+    corr_n = core._lse_correction(q.transpose(1, 2), km.transpose(1, 2), "NHD")
+    assert corr_n.shape == (2, 4, 10) and torch.equal(corr_n, corr)
     assert core._smooth_k(q, k, "HND", False, True) == (None, None)
 
 
