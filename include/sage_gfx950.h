@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 2
+#define SAGE_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -178,6 +178,27 @@ SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const vo
                              int64_t o_sb, int64_t o_sh, int64_t o_sl,
                              int is_causal, int qk_quant_gran, int q_warp,
                              float sm_scale_log2, int pv_accum, int out_dtype, void *stream);
+
+/* attn_mask kinds of sage_attn_qk_int8_pv_f16_masked */
+#define SAGE_MASK_BOOL 1      /* 1 byte per element, non-zero = attend           */
+#define SAGE_MASK_F16 2       /* additive, fp16                                   */
+#define SAGE_MASK_BF16 3      /* additive, bf16                                   */
+
+/* FP16-PV attention with an attention mask, non-causal, per-block scales (sm_scale*log2e folded into Q).
+ * Replaces: the Triton `forward(..., attn_mask=...)` op (triton/attn_qk_int8_per_block.py:31-51,130-183).
+ * mask is addressed as mask[b*m_sb + h*m_sh + q*m_sq + k*m_sk] (element strides; 0 = broadcast, as
+ * `attn_mask.expand(...)` produces, core.py:313-322).  Semantics mirror the reference: bool -> 0 / -1e6
+ * added to the score and a 128x64 tile whose mask block is all False is skipped; float -> the mask value
+ * is added to the (log2-domain) score; out-of-range positions count as False / -1e6. */
+SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                    const float *q_scale, const float *k_scale,
+                                    const void *mask, int mask_kind,
+                                    int64_t m_sb, int64_t m_sh, int64_t m_sq, int64_t m_sk,
+                                    int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                    int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                                    int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                    int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                    float sm_scale_log2, int out_dtype, void *stream);
 
 /* Variable-length fused attention (per-block scales, FP16 PV), packed q/o [sum Lq, Hq, D],
  * k [sum Lk, Hkv, D].  Replaces: attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125.

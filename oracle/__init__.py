@@ -138,7 +138,7 @@ def v_mean_padded16(v: np.ndarray, dtype: int) -> np.ndarray:
 
 
 def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float, pv_mode: int,
-         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False):
+         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False, mask_bool=None, mask_add=None):
     """Fused attention on quantised operands; returns (o bits uint16 [B,Hq,Lq,D], lse|None)."""
     B, Hq, Lq, D = q8.shape
     _, Hkv, Lk, _ = k8.shape
@@ -150,6 +150,8 @@ def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float,
                         _p(q_scale), _p(q_sidx), int(q_scale.shape[-1]),
                         _p(k_scale), _p(k_sidx), int(k_scale.shape[-1]), _p(v_scale),
                         _p(None if v_mean is None else np.ascontiguousarray(v_mean, dtype=np.float32)),
+                        _p(None if mask_bool is None else np.ascontiguousarray(np.broadcast_to(mask_bool, (B, Hq, Lq, Lk)), dtype=np.uint8)),
+                        _p(None if mask_add is None else np.ascontiguousarray(np.broadcast_to(mask_add, (B, Hq, Lq, Lk)), dtype=np.float32)),
                         int(B), int(Hq), int(Hkv), int(Lq), int(Lk), int(D), int(causal),
                         ctypes.c_float(float(c)), int(pv_mode), int(out_dtype))
     assert rc == 0, "orc_attn rejected the arguments"
@@ -179,7 +181,7 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
                    qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32,
-                   smooth_v=False, vm=None):
+                   smooth_v=False, vm=None, mask_bool=None, mask_add=None):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -241,7 +243,8 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
             vh = convert(to_f32(v, dtype) - vm[:, :, None, :], "f16")
             aux.update(vm=vm)
         o, lse = attn(q8, k8, vh, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=mode,
-                      out_dtype=dtype, v_mean=vm if smooth_v else None, return_lse=return_lse)
+                      out_dtype=dtype, v_mean=vm if smooth_v else None, return_lse=return_lse,
+                      mask_bool=mask_bool, mask_add=mask_add)
     o = np.ascontiguousarray(o[..., :D0])
     if return_lse:
         lse = lse / np.float32(LOG2E)

@@ -275,6 +275,10 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  * Tiles: 128 query rows x 64 keys (attn_qk_int8_per_block.py:131-132).
  * lse (nullable) [B,Hq,Lq] = log2(l) + m, log2 units (attn_qk_int8_per_block.py:126-127).
  * out dtype: 0 fp16, 1 bf16.
+ * mask_b / mask_f (at most one non-NULL, [B,Hq,Lq,Lk], non-causal only): attn_mask of the Triton path
+ *   (attn_qk_int8_per_block.py:31-51).  bool: a 128x64 tile whose mask block is all False is skipped
+ *   (:36-38), otherwise 0 / -1e6 is added to the score (:47-48); float: the value is added (:49-50);
+ *   out-of-range keys load as False / -1e6 (`other=`), i.e. their score is exactly -1e6 (K loads as 0).
  */
 #define BM 128
 #define BN 64
@@ -284,6 +288,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         const float *q_scale, const int32_t *q_sidx, int nqs,
                         const float *k_scale, const int32_t *k_sidx, int nks,
                         const float *v_scale, const float *v_mean,
+                        const uint8_t *mask_b, const float *mask_f,
                         int B, int Hq, int Hkv, int Lq, int Lk, int D,
                         int causal, float c, int pv_mode, int out_dtype)
 {
@@ -318,9 +323,18 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                 memset(acc, 0, sizeof(float) * BM * 128);
                 int kend = Lk;
                 if (causal && (r0 + BM) < kend) kend = r0 + BM;
+                const int masked = (mask_b != NULL) || (mask_f != NULL);
+                const size_t mo = ((size_t)(b * Hq + h) * Lq) * Lk;
                 for (int n0 = 0; n0 < kend; n0 += BN) {
                     const int nk = (kend - n0 < BN) ? kend - n0 : BN;
                     const int nkv = (Lk - n0 < BN) ? Lk - n0 : BN;   /* keys that exist */
+                    if (mask_b) {
+                        int any = 0;
+                        for (int i = 0; i < rows && !any; i++)
+                            for (int j = 0; j < nkv; j++)
+                                if (mask_b[mo + (size_t)(r0 + i) * Lk + n0 + j]) { any = 1; break; }
+                        if (!any) continue;
+                    }
                     for (int i = 0; i < rows; i++) {
                         const int8_t *qr = qp + (size_t)(r0 + i) * D;
                         const float qsc = qs[q_sidx[r0 + i]];
@@ -332,7 +346,9 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                                 int32_t dot = 0;
                                 for (int d = 0; d < D; d++) dot += (int32_t)qr[d] * (int32_t)kr[d];
                                 s = (float)dot * (qsc * ks[k_sidx[n0 + j]]) * c;
-                            }
+                                if (mask_b) s += mask_b[mo + (size_t)(r0 + i) * Lk + n0 + j] ? 0.0f : -1.0e6f;
+                                if (mask_f) s += mask_f[mo + (size_t)(r0 + i) * Lk + n0 + j];
+                            } else if (masked) s = -1.0e6f;
                             p[i][j] = s;
                             mx = fmaxf(mx, s);
                         }

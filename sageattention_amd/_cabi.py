@@ -14,11 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
 PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL = 0, 1
+MASK_BOOL, MASK_F16, MASK_BF16 = 1, 2, 3
 
 # every symbol include/sage_gfx950.h declares: name -> (restype, argtypes)
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
@@ -39,6 +40,8 @@ SYMBOLS = {
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
     "sage_attn_qk_int8_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+    "sage_attn_qk_int8_pv_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I,
+                                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P]),
     "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
 }

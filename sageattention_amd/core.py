@@ -96,6 +96,30 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     return o, lse
 
 
+def _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, out_dtype, tensor_layout, return_lse):
+    """Triton-named API with ``attn_mask`` (core.py:313-324): the mask is broadcast to
+    ``[B, Hq, Lq, Lk]`` by ``expand`` (zero strides, no copy) and read in place by the kernel."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q_int8, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
+    assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
+    target_shape = (B, Hq, Lq, Lk)
+    try:
+        attn_mask = attn_mask.expand(target_shape)
+    except Exception:
+        raise AssertionError(f"attn_mask shape {attn_mask.shape} cannot be broadcast to {target_shape}")
+    kind = _cabi.MASK_BOOL if attn_mask.dtype == torch.bool else (_cabi.MASK_F16 if attn_mask.dtype == torch.float16 else _cabi.MASK_BF16)
+    o = torch.empty(q_int8.shape, dtype=out_dtype, device=q_int8.device)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=o.device) if return_lse else None
+    code = _cabi.DTYPE_F16 if out_dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_qk_int8_pv_f16_masked(
+        _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale), _p(attn_mask), kind,
+        attn_mask.stride(0), attn_mask.stride(1), attn_mask.stride(2), attn_mask.stride(3),
+        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, 1.0, code, _stream(o))
+    _cabi.check(rc, "sage_attn_qk_int8_pv_f16_masked")
+    return o, lse
+
+
 def _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale):
     o = o[..., :head_dim_og]
     if return_lse:   # core.py:328-329: kernel LSE is in log2 units
@@ -128,7 +152,8 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     dtype = q.dtype
     _check_inputs(q, k, v)
     if attn_mask is not None:
-        raise NotImplementedError("attn_mask is not supported by the gfx950 kernels yet")
+        assert attn_mask.dtype == torch.bool or attn_mask.dtype == q.dtype, "attn_mask must be of dtype bool or the same dtype as q."
+        assert attn_mask.device == q.device, "All tensors must be on the same device."
     if quantization_backend not in ("triton", "cuda"):
         raise ValueError(f"Unsupported quantization backend: {quantization_backend}")
     torch.cuda.set_device(v.device)
@@ -143,8 +168,13 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     q_int8, q_scale, k_int8, k_scale = per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
                                                       quantization_backend=quantization_backend)
     v_image = prep_v_fp16(v, tensor_layout)
-    o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         _cabi.GRAN_PER_BLOCK, 128, 1.0, True, return_lse)
+    if is_causal:
+        assert attn_mask is None, "Mask should be None for causal attention."        # core.py:310
+    if attn_mask is not None:
+        o, lse = _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, dtype, tensor_layout, return_lse)
+    else:
+        o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
+                             _cabi.GRAN_PER_BLOCK, 128, 1.0, True, return_lse)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 

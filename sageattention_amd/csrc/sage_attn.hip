@@ -63,7 +63,7 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 // c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
+template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL))
 sage_attn_kernel(const AttnParams p)
 {
@@ -306,11 +306,37 @@ sage_attn_kernel(const AttnParams p)
             const int key0 = it * KT + hh * BLKK;
             if (key0 < Lk && (!CAUSAL || key0 <= row0 + 31)) nact = hh + 1;
         }
-        if (nact > 0) {
+        // ---- attn_mask (Triton-named API only; attn_qk_int8_per_block.py:31-51): additive term per
+        //      score in the log2 domain.  bool: 0 / -1e6, and a tile whose whole 128x64 mask block is
+        //      False is skipped; float: the mask value itself; out-of-range positions count as False / -1e6.
+        float mk[MASK ? NS : 1][16];
+        bool skip_tile = false;
+        if constexpr (MASK != 0) {
+            const unsigned char *mbase = reinterpret_cast<const unsigned char *>(p.mask);
+            const long mrow = (long)b * p.m_sb + (long)h * p.m_sh + (long)my_row * p.m_sq;
+            int anytrue = 0;
+#pragma unroll
+            for (int sb = 0; sb < NS; sb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int key = it * KT + sb * 32 + crow(i, g);
+                    const bool inb = (my_row < Lq) && (key < Lk);
+                    float add = -1.0e6f;
+                    if (inb) {
+                        const long idx = mrow + (long)key * p.m_sk;
+                        if (MASK == 1) { const bool t = mbase[idx] != 0; add = t ? 0.0f : -1.0e6f; anytrue |= (int)t; }
+                        else if (MASK == 2) add = f16_to_f32(reinterpret_cast<const uint16_t *>(mbase)[idx]);
+                        else add = bf16_to_f32(reinterpret_cast<const uint16_t *>(mbase)[idx]);
+                    }
+                    mk[sb][i] = add;
+                }
+            if (MASK == 1) skip_tile = !__syncthreads_or(anytrue);
+        }
+        if (nact > 0 && !skip_tile) {
             const unsigned char *ks = smem + cur * C::STAGE_BYTES;
             const unsigned char *vs = ks + C::K_TILE_BYTES;
             const int last_key = it * KT + nact * BLKK - 1;
-            const bool full = (nact == NH) && !(CAUSAL && last_key > row0) && (last_key < Lk);
+            const bool full = (MASK == 0) && (nact == NH) && !(CAUSAL && last_key > row0) && (last_key < Lk);
 
             // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
             v16i s[NS];
@@ -367,7 +393,8 @@ sage_attn_kernel(const AttnParams p)
                             const float cc = cs[sb >> 1][(KTHREAD && (i & 2)) ? 1 : 0];
                             const int key = it * KT + sb * 32 + crow(i, g);
                             const bool ok = (key < Lk) && (!CAUSAL || key <= my_row);
-                            mx = fmaxf(mx, ok ? (float)s[sb][i] * cc : -INFINITY);
+                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? (float)s[sb][i] * cc : 0.0f) + mk[sb][i]);
+                            else mx = fmaxf(mx, ok ? (float)s[sb][i] * cc : -INFINITY);
                         }
                     }
                 m_new = fmaxf(m_run, pair_max(mx) - OFF);
@@ -390,11 +417,17 @@ sage_attn_kernel(const AttnParams p)
                 for (int j = 0; j < 8; j++) {
                     const int i = r0 + j;
                     const float cc = cs[hh][(KTHREAD && (i & 2)) ? 1 : 0];
-                    float v = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[sb][i], cc, -m_new));
-                    if constexpr (decltype(masked)::value) {
+                    float v;
+                    if constexpr (MASK != 0) {
                         const int key = it * KT + sb * 32 + crow(i, g);
-                        const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= my_row);
-                        v = ok ? v : 0.0f;
+                        v = __builtin_amdgcn_exp2f(((key < Lk) ? (float)s[sb][i] * cc : 0.0f) + mk[sb][i] - m_new);
+                    } else {
+                        v = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[sb][i], cc, -m_new));
+                        if constexpr (decltype(masked)::value) {
+                            const int key = it * KT + sb * 32 + crow(i, g);
+                            const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= my_row);
+                            v = ok ? v : 0.0f;
+                        }
                     }
                     e[j] = v;
                     rs += v;
@@ -588,11 +621,28 @@ static hipError_t launch_d(const AttnParams &p, int nwork, bool causal, bool kth
     return hipErrorInvalidValue;
 }
 
+template <int D, int MASK>
+static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stream)
+{
+    using C = TileCfg<D, false, 1>;
+    auto kern = sage_attn_kernel<D, false, false, false, true, 1, MASK>;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
-                       bool two_level, hipStream_t stream)
+                       bool two_level, int mask_kind, hipStream_t stream)
 {
     const int nwork = p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
+    if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
+        if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)
+            return hipErrorInvalidValue;
+        if (head_dim == 128) return mask_kind == 1 ? launch_masked<128, 1>(p, nwork, stream)
+                                  : mask_kind == 2 ? launch_masked<128, 2>(p, nwork, stream) : launch_masked<128, 3>(p, nwork, stream);
+        return mask_kind == 1 ? launch_masked<64, 1>(p, nwork, stream)
+             : mask_kind == 2 ? launch_masked<64, 2>(p, nwork, stream) : launch_masked<64, 3>(p, nwork, stream);
+    }
     // keys per iteration: 128 where two workgroups still fit a CU's LDS, else 64
     if (head_dim == 128) return pv_fp8 ? launch_d<128, true, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream)
                                        : launch_d<128, false, 1>(p, nwork, causal, kthread, two_level, stream);

@@ -30,13 +30,16 @@ int check_launch(hipError_t e, const char *what)
 
 #define SAGE_REQUIRE(cond, ...) do { if (!(cond)) return fail(SAGE_EINVAL, __VA_ARGS__); } while (0)
 
+struct MaskArg { const void *ptr; int kind; int64_t sb, sh, sq, sk; };
+
 int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
                 const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
                 const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_qs, const int32_t *cu_ks,
                 int B, int Hq, int Hkv, int Lq, int Lk, int D,
                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+                int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream,
+                const MaskArg *mask = nullptr)
 {
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -78,7 +81,15 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     p.out_dtype = out_dtype;
     p.lse_sh = 0;
     p.sm_scale_log2 = sm_scale_log2;
-    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, pv_accum == SAGE_PV_ACCUM_TWO_LEVEL,
+    int mask_kind = 0;
+    if (mask != nullptr) {
+        SAGE_REQUIRE(mask->ptr, "null attn_mask pointer");
+        SAGE_REQUIRE(mask->kind >= SAGE_MASK_BOOL && mask->kind <= SAGE_MASK_BF16, "bad mask_kind %d", mask->kind);
+        SAGE_REQUIRE(!is_causal, "Mask should be None for causal attention.");           // core.py:310
+        p.mask = mask->ptr; p.m_sb = mask->sb; p.m_sh = mask->sh; p.m_sq = mask->sq; p.m_sk = mask->sk;
+        mask_kind = mask->kind;
+    }
+    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, pv_accum == SAGE_PV_ACCUM_TWO_LEVEL, mask_kind,
                                           static_cast<hipStream_t>(stream)), "sage_attn launch");
 }
 
@@ -256,6 +267,19 @@ SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const vo
     return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, v_mean, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
                        is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream);
+}
+
+SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                    const float *q_scale, const float *k_scale, const void *mask, int mask_kind,
+                                    int64_t m_sb, int64_t m_sh, int64_t m_sq, int64_t m_sk,
+                                    int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                    int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                    int64_t o_sb, int64_t o_sh, int64_t o_sl, float sm_scale_log2, int out_dtype, void *stream)
+{
+    const MaskArg m{mask, mask_kind, m_sb, m_sh, m_sq, m_sk};
+    return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+                       0, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, SAGE_PV_ACCUM_TWO_LEVEL, out_dtype, stream, &m);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,

@@ -18,6 +18,8 @@ struct AttnParams {
     const float *k_scale;
     const float *v_scale;     // [B,Hkv,D] (fp8 PV) or null
     const float *v_mean;      // [B,Hkv,D] or null
+    const void *mask;         // attn_mask (bool bytes or fp16/bf16 additive), element strides below; null = none
+    long m_sb, m_sh, m_sq, m_sk;
     const int32_t *cu_q;      // varlen only (null => dense)
     const int32_t *cu_k;
     const int32_t *cu_qs;     // prefix sums of ceil(Lq_i/128)
@@ -36,8 +38,9 @@ struct AttnParams {
     float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain
 };
 
+// mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
-                       bool two_level, hipStream_t stream);
+                       bool two_level, int mask_kind, hipStream_t stream);
 
 // ---- INT8 quantisation of Q / K ----------------------------------------------------------------
 enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style

@@ -45,7 +45,7 @@ def bits(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
 
 
-def ref_dense(q, k, v, is_causal, sm_scale=None, smooth_k=True, return_lse=True):
+def ref_dense(q, k, v, is_causal, sm_scale=None, smooth_k=True, return_lse=True, attn_mask=None):
     """core.py:242-331 with tensor_layout="HND", quantization_backend="triton"."""
     dtype = q.dtype
     head_dim_og = q.size(-1)
@@ -67,7 +67,10 @@ def ref_dense(q, k, v, is_causal, sm_scale=None, smooth_k=True, return_lse=True)
     if is_causal:
         o, lse = attn_c.forward(q_int8, k_int8, v, q_scale, k_scale, tensor_layout="HND", output_dtype=dtype, return_lse=return_lse)
     else:
-        o, lse = attn_nc.forward(q_int8, k_int8, v, q_scale, k_scale, tensor_layout="HND", output_dtype=dtype, return_lse=return_lse)
+        if attn_mask is not None:      # core.py:313-322
+            attn_mask = attn_mask.expand((q.shape[0], q.shape[1], q.shape[2], k.shape[2]))
+        o, lse = attn_nc.forward(q_int8, k_int8, v, q_scale, k_scale, tensor_layout="HND", output_dtype=dtype, attn_mask=attn_mask,
+                                 return_lse=return_lse)
     o = o[..., :head_dim_og]
     if return_lse:
         lse = lse / 1.44269504 + lse_correction * sm_scale if smooth_k else lse / 1.44269504
@@ -123,6 +126,27 @@ def dense_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, causal, kbias=0.0, seed=0):
     save(name, **arrs)
 
 
+def mask_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, kind, seed=0):
+    """Triton API with attn_mask (bool or additive in the dtype of q), non-causal."""
+    torch.manual_seed(seed)
+    q = torch.randn(B, Hq, Lq, D).to(dtype)
+    k = (torch.randn(B, Hkv, Lk, D) + torch.randn(1, Hkv, 1, D)).to(dtype)
+    v = torch.randn(B, Hkv, Lk, D).to(dtype)
+    if kind == "bool":
+        mask = torch.rand(B, 1, Lq, Lk) > 0.35
+        mask[:, :, :128, 64:128] = False           # a whole 128x64 block that must be skipped
+        mask[:, :, 130:140, :] = False              # fully masked rows
+        mask[:, :, :, 0] |= torch.rand(B, 1, Lq) > 0.1
+        mask[:, :, 130:140, :] = False
+    else:
+        mask = (2.0 * torch.randn(1, Hq, Lq, Lk)).to(dtype)
+        mask[:, :, :, 5:9] = -30000.0
+    o, lse, aux = ref_dense(q, k, v, False, attn_mask=mask)
+    m = mask.numpy() if kind == "bool" else bits(mask)
+    save(name, q=bits(q), k=bits(k), v=bits(v), o=bits(o), lse=lse.numpy(), mask=m,
+         meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64))
+
+
 def varlen_case(name, lens, Hq, Hkv, D, dtype, causal, seed=0):
     torch.manual_seed(seed)
     total = sum(lens)
@@ -152,6 +176,10 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present; golden vectors can only be generated in the build container")
     f16, bf16 = torch.float16, torch.bfloat16
+    if len(sys.argv) > 1 and sys.argv[1] == "--masks-only":
+        mask_case("mask_bool_lq300_lk333_d64_f16", 2, 4, 2, 300, 333, 64, f16, "bool", seed=8)
+        mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)
+        sys.exit(0)
     dense_case("c1_b1h4n512d64_f16", 1, 4, 4, 512, 512, 64, f16, False)             # BASELINE.json configs[0]
     dense_case("gqa_causal_n300d128_bf16", 1, 4, 2, 300, 300, 128, bf16, True, kbias=2.0, seed=1)
     dense_case("cross_lq200_lk333_d64_f16", 2, 2, 2, 200, 333, 64, f16, False, kbias=1.0, seed=2)
@@ -161,3 +189,5 @@ if __name__ == "__main__":
     varlen_case("varlen_c_d64_f16", [100, 257, 64], 4, 2, 64, f16, True, seed=5)
     varlen_case("varlen_c_d128_bf16", [130, 64, 300], 4, 1, 128, bf16, True, seed=6)
     per_thread_case("per_thread_quant_d128_f16", 1, 2, 1, 200, 150, 128, f16, seed=7)
+    mask_case("mask_bool_lq300_lk333_d64_f16", 2, 4, 2, 300, 333, 64, f16, "bool", seed=8)
+    mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)

@@ -269,6 +269,28 @@ def test_triton_api_vs_reference_golden(name, layout):
         assert (qs.cpu().numpy() == z["q_scale"]).all() and (ks.cpu().numpy() == z["k_scale"]).all()
 
 
+@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add")])
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+def test_attn_mask_vs_reference_golden(name, kind, layout):
+    """sageattn_qk_int8_pv_fp16_triton(attn_mask=...) against the reference Triton kernel's output, incl. the
+    all-False-tile skip, fully masked rows and a broadcast (stride-0) mask."""
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden(name)
+    q, k, v = (to_dev(util.from_bits(z[n], dt), layout) for n in ("q", "k", "v"))
+    mask = torch.from_numpy(z["mask"]).to(DEV) if kind == "bool" else util.from_bits(z["mask"], dt, DEV)
+    o, lse = sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, attn_mask=mask, return_lse=True)
+    torch.cuda.synchronize()
+    got, ref = to_hnd(o, layout).float().cpu().numpy(), util.f32(z["o"], dt)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    REPORT[f"golden/{name}/{layout}"] = dict(max_abs=err, max_o=scale)
+    assert np.isfinite(got).all()
+    assert err <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
+    # fully masked rows carry an LSE of about -1e6/log2e where one fp32 ulp is 0.0625
+    assert (np.abs(lse.cpu().numpy() - z["lse"]) <= 2e-2 + 2e-7 * np.abs(z["lse"])).all()
+    with pytest.raises(AssertionError):
+        sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, attn_mask=mask, is_causal=True)
+
+
 @pytest.mark.parametrize("name", ["varlen_nc_d64_f16", "varlen_c_d64_f16", "varlen_c_d128_bf16"])
 def test_varlen_vs_reference_golden(name):
     z, (nseq, Hq, Hkv, total, _, D, dt, causal) = util.golden(name)

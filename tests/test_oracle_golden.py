@@ -51,6 +51,18 @@ def test_varlen_matches_reference(oracle_mod, name):
     assert np.abs(of - rf).max() <= tol
 
 
+@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add")])
+def test_attn_mask_matches_reference(oracle_mod, name, kind):
+    """Triton API attn_mask semantics (bool 0/-1e6 + all-False tile skip, additive float), incl. fully masked rows."""
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden(name)
+    kw = dict(mask_bool=z["mask"]) if kind == "bool" else dict(mask_add=util.f32(z["mask"], dt))
+    o, lse, _ = oracle_mod.sageattn_dense(z["q"], z["k"], z["v"], dt, pv="f16_triton", return_lse=True, **kw)
+    of, rf = util.f32(o, dt), util.f32(z["o"], dt)
+    tol = (2 ** -10 if dt == 0 else 2 ** -7) * max(1.0, float(np.abs(rf).max()))
+    assert np.abs(of - rf).max() <= tol
+    assert np.abs(lse - z["lse"]).max() < 1e-4
+
+
 def test_per_thread_quant_matches_reference(oracle_mod):
     z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden("per_thread_quant_d128_f16")
     gq, nq = oracle_mod.group_index(Lq, "per_thread", "q", 128, 32)
