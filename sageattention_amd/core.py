@@ -18,7 +18,7 @@ from typing import Any, Optional
 import torch
 import torch.nn.functional as F
 
-from . import _cabi
+from . import _cabi, ops
 from .quant import (LOG2E, _dims, _p, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
                     per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, sub_mean)
 
@@ -71,29 +71,20 @@ def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
 
 def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dtype, tensor_layout, is_causal,
                 gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None):
-    """Allocate ``o`` (+ ``lse``) and launch the fused kernel through the C ABI."""
-    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q_int8, tensor_layout)
-    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
+    """Allocate ``o`` and launch the fused kernel through the registered custom op (-> C ABI)."""
+    B, Hq, Lq, D, _, _, _ = _dims(q_int8, tensor_layout)
+    Hkv = _dims(k_int8, tensor_layout)[1]
     assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
     o = torch.empty(q_int8.shape, dtype=out_dtype, device=q_int8.device)
-    _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
-    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=o.device) if return_lse else None
-    code = _cabi.DTYPE_F16 if out_dtype == torch.float16 else _cabi.DTYPE_BF16
+    layout = 0 if tensor_layout == "NHD" else 1            # the reference's encoding (core.py:556)
     accum = _cabi.PV_ACCUM_TWO_LEVEL if two_level else _cabi.PV_ACCUM_SINGLE
-    lib = _cabi.load()
     if fp8:
-        rc = lib.sage_attn_qk_int8_pv_f8(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
-                                         _p(v_scale), _p(v_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
-                                         o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
-                                         _stream(o))
-        _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
+        lse = ops.qk_int8_sv_f8_attn(q_int8, k_int8, v_image, o, q_scale, k_scale, v_scale, v_mean, layout, int(is_causal),
+                                     gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
     else:
-        rc = lib.sage_attn_qk_int8_pv_f16(_p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale),
-                                          _p(v_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
-                                          o_sb, o_sh, o_sl, int(is_causal), gran, q_warp, float(sm_scale_log2), accum, code,
-                                          _stream(o))
-        _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
-    return o, lse
+        lse = ops.qk_int8_sv_f16_attn(q_int8, k_int8, v_image, o, q_scale, k_scale, v_mean, layout, int(is_causal),
+                                      gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
+    return o, (lse if return_lse else None)
 
 
 def _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, out_dtype, tensor_layout, return_lse):

@@ -1,0 +1,86 @@
+"""torch.library registration of the fused attention ops (the reference's ``sm80_compile.py`` /
+``sm89_compile.py`` / ``sm90_compile.py`` convention): ``custom_op(..., mutates_args=("output",))`` plus
+a fake (shape-only) implementation, so ``torch.compile`` can trace through ``sageattn`` in
+non-fullgraph / no-cudagraph mode exactly as the reference documents (README.md:30, core.py:252-257).
+
+The ops are thin: they forward data pointers, shapes and strides to the C ABI (``include/sage_gfx950.h``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _cabi
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dims(t: torch.Tensor, tensor_layout: int):
+    # tensor_layout encoding of the reference's op boundary: 0 = NHD, 1 = HND (core.py:556)
+    if tensor_layout == 1:
+        B, H, L, D = t.shape
+        return B, H, L, D, t.stride(0), t.stride(1), t.stride(2)
+    B, L, H, D = t.shape
+    return B, H, L, D, t.stride(0), t.stride(2), t.stride(1)
+
+
+def _lse_alloc(query: torch.Tensor, tensor_layout: int, return_lse: int) -> torch.Tensor:
+    B, H, L, _, _, _, _ = _dims(query, tensor_layout)
+    if return_lse:
+        return torch.empty((B, H, L), dtype=torch.float32, device=query.device)
+    return torch.empty((0,), dtype=torch.float32, device=query.device)      # reference: torch::empty({0})
+
+
+@torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f8_attn", mutates_args=("output",), device_types="cuda")
+def qk_int8_sv_f8_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
+                       query_scale: torch.Tensor, key_scale: torch.Tensor, value_scale: torch.Tensor,
+                       value_mean: Optional[torch.Tensor], tensor_layout: int, is_causal: int, qk_quant_gran: int,
+                       q_warp: int, sm_scale_log2: float, pv_accum: int, return_lse: int) -> torch.Tensor:
+    """INT8 QK^T + FP8 PV (replaces the sm89/sm90 ops, sm89_compile.py:5-146, sm90_compile.py:5-94)."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(query, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(key, tensor_layout)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(output, tensor_layout)
+    lse = _lse_alloc(query, tensor_layout, return_lse)
+    code = _cabi.DTYPE_F16 if output.dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_qk_int8_pv_f8(
+        _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
+        _p(value_scale), _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+        is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
+        torch.cuda.current_stream(output.device).cuda_stream)
+    _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
+    return lse
+
+
+@qk_int8_sv_f8_attn.register_fake
+def _(query, key, v_image, output, query_scale, key_scale, value_scale, value_mean, tensor_layout, is_causal,
+      qk_quant_gran, q_warp, sm_scale_log2, pv_accum, return_lse):
+    return _lse_alloc(query, tensor_layout, return_lse)
+
+
+@torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f16_attn", mutates_args=("output",), device_types="cuda")
+def qk_int8_sv_f16_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
+                        query_scale: torch.Tensor, key_scale: torch.Tensor, value_mean: Optional[torch.Tensor],
+                        tensor_layout: int, is_causal: int, qk_quant_gran: int, q_warp: int, sm_scale_log2: float,
+                        pv_accum: int, return_lse: int) -> torch.Tensor:
+    """INT8 QK^T + FP16 PV (replaces the sm80 ops, sm80_compile.py:5-149, and the Triton forward)."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(query, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(key, tensor_layout)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(output, tensor_layout)
+    lse = _lse_alloc(query, tensor_layout, return_lse)
+    code = _cabi.DTYPE_F16 if output.dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_qk_int8_pv_f16(
+        _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
+        _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+        is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
+        torch.cuda.current_stream(output.device).cuda_stream)
+    _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
+    return lse
+
+
+@qk_int8_sv_f16_attn.register_fake
+def _(query, key, v_image, output, query_scale, key_scale, value_mean, tensor_layout, is_causal, qk_quant_gran, q_warp,
+      sm_scale_log2, pv_accum, return_lse):
+    return _lse_alloc(query, tensor_layout, return_lse)

@@ -379,6 +379,19 @@ def test_non_default_stream_and_reentrancy():
         assert torch.equal(o, ref)          # deterministic: same bits on any stream, any repetition
 
 
+def test_torch_compile_traces_through_the_custom_ops():
+    """README.md:30 of the reference: torch.compile in non-fullgraph mode; the fused ops are custom_ops with fakes."""
+    q, k, v = (t.to(DEV) for t in rand_qkv(1, 4, 4, 256, 256, 64, 0, seed=17))
+
+    def block(q, k, v):
+        return sa.sageattn(q * 1.0, k, v, is_causal=True) + 1.0
+
+    want = block(q, k, v)
+    got = torch.compile(block, backend="aot_eager")(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE.json full sizes
 def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
     o_full = fn(q, k, v, is_causal=causal)

@@ -56,3 +56,20 @@ def test_shard_units_partition():
             assert seen == list(range(B * H // g))
     sizes = [shard.shard_range(64, r, 8) for r in range(8)]
     assert all(hi - lo == 8 for lo, hi in sizes)
+
+
+def test_custom_ops_registered_with_fake_impl():
+    """sm80/sm89/sm90_compile.py convention: custom_op + register_fake so torch.compile can trace (shape-only here)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from sageattention_amd import ops  # noqa: F401
+    with FakeTensorMode():
+        dev = "cuda"
+        q = torch.empty(2, 300, 4, 128, dtype=torch.int8, device=dev)       # NHD
+        k = torch.empty(2, 300, 2, 128, dtype=torch.int8, device=dev)
+        v = torch.empty(2, 2, 5, 128, 64, dtype=torch.uint8, device=dev)
+        o = torch.empty(2, 300, 4, 128, dtype=torch.bfloat16, device=dev)
+        qs = torch.empty(2, 4, 96, device=dev); ks = torch.empty(2, 2, 20, device=dev); vs = torch.empty(2, 2, 128, device=dev)
+        lse = torch.ops.sageattention_gfx950.qk_int8_sv_f8_attn(q, k, v, o, qs, ks, vs, None, 0, 1, 3, 32, 0.1, 1, 1)
+        assert lse.shape == (2, 4, 300) and lse.dtype == torch.float32
+        lse0 = torch.ops.sageattention_gfx950.qk_int8_sv_f16_attn(q, k, v, o, qs, ks, None, 0, 0, 2, 32, 0.1, 0, 0)
+        assert lse0.numel() == 0
