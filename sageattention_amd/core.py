@@ -87,6 +87,7 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     return o, (lse if return_lse else None)
 
 
+@torch.compiler.disable
 def _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, out_dtype, tensor_layout, return_lse):
     """Triton-named API with ``attn_mask`` (core.py:313-324): the mask is broadcast to
     ``[B, Hq, Lq, Lk]`` by ``expand`` (zero strides, no copy) and read in place by the kernel."""
@@ -169,6 +170,7 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
+@torch.compiler.disable
 def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, is_causal: bool = False,
                     sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any) -> torch.Tensor:
     """Variable-length batches, q/k/v packed as ``[sum L, H, D]`` (reference core.py:334-448)."""

@@ -37,13 +37,16 @@
 #ifndef SAGE_MXPV       // FP8 PV on the block-scaled K=64 MFMA with unit scales (+5%)
 #define SAGE_MXPV 1
 #endif
+#ifndef SAGE_STAGES     // LDS ring depth: 3 = two tiles in flight, counted vmcnt + raw s_barrier (needs SAGE_GLDS)
+#define SAGE_STAGES 3
+#endif
 #ifndef SAGE_NH_F8      // 64-key images per iteration (2 = 128-key tiles: spills at D=128 today)
 #define SAGE_NH_F8 1
 #endif
 
 #ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow: 3 (<= 168 VGPRs,
                         // +3.5% measured) wherever that does not spill, i.e. everything except FP16 PV at D=128 and FP8 single-level per-thread
-#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL) ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2)
+#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) ((MASK) != 0 ? 2 : ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2))
 #endif
 
 namespace sage {
@@ -55,7 +58,8 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
     static constexpr int V_IMG_BYTES = D * V_ROW_BYTES;
     static constexpr int STAGE_BYTES = K_TILE_BYTES + NH * V_IMG_BYTES;
     static constexpr int O_BYTES = BLKQ * D * 2;
-    static constexpr int LDS_BYTES = (2 * STAGE_BYTES > O_BYTES) ? 2 * STAGE_BYTES : O_BYTES;
+    static constexpr int NSTAGE = (SAGE_GLDS && SAGE_STAGES == 3) ? 3 : 2;
+    static constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > O_BYTES) ? NSTAGE * STAGE_BYTES : O_BYTES;
     static constexpr int KSTEPS = D / 32;                       // i8 MFMA k-steps over head dim
     static constexpr int DT = D / 32;                           // 32-wide output d tiles
 };
@@ -64,7 +68,7 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0>
-__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL))
+__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
 sage_attn_kernel(const AttnParams p)
 {
     using C = TileCfg<D, PV_FP8, NH>;
@@ -264,9 +268,12 @@ sage_attn_kernel(const AttnParams p)
     float m_run = kNegBig, l_run = 0.0f;
     constexpr float OFF = PV_FP8 ? kFp8Offset : 0.0f;
 
-    // K scales of the current iteration, loaded one iteration ahead and BEFORE that iteration's
-    // LDS-DMA is issued: an ordinary VMEM load issued after the DMA would make its s_waitcnt
-    // vmcnt(0) drain the in-flight tile too (vmcnt retires in order).
+    // K scales of an iteration are fetched one iteration ahead with SCALAR loads (constant address
+    // space, wave-uniform index -> s_load, tracked by lgkmcnt).  An ordinary VMEM load here would be
+    // fatal for the pipeline: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use of any
+    // VGPR-destination load, draining the in-flight tiles every iteration.
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    const cfloat_p ks_c = (cfloat_p)(ks_ptr);
     float ksc[NH][2];
     auto load_kscales = [&](int it, float (&dst)[NH][2]) {
 #pragma unroll
@@ -274,12 +281,32 @@ sage_attn_kernel(const AttnParams p)
             int tk = it * NH + hh;
             tk = tk < ntk_all ? tk : ntk_all - 1;
             const long tb = (long)tk * ks_tstride;
-            if (KTHREAD) {      // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83)
-                dst[hh][0] = ks_ptr[tb + 2 * g];
-                dst[hh][1] = ks_ptr[tb + 2 * g + 1];
+            if (KTHREAD) {      // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83); lane half g uses 2g, 2g+1
+                const float s0 = ks_c[tb], s1 = ks_c[tb + 1], s2 = ks_c[tb + 2], s3 = ks_c[tb + 3];
+                dst[hh][0] = g ? s2 : s0;
+                dst[hh][1] = g ? s3 : s1;
             } else {
-                dst[hh][0] = dst[hh][1] = ks_ptr[tb];
+                dst[hh][0] = dst[hh][1] = ks_c[tb];
             }
+        }
+    };
+    // LDS ring.  NSTAGE == 3: tiles it+1 and it+2 are in flight while tile it is consumed; a wave waits
+    // only for ITS OWN older DMA group with a counted s_waitcnt vmcnt(N) (N = DMA instructions of the
+    // younger group) and then meets the others at a raw s_barrier -- __syncthreads() would drain
+    // vmcnt(0) and expose the full L2/HBM latency every iteration (cdna_hip_programming.md T3+T4).
+    constexpr int NSTAGE = C::NSTAGE;
+#if SAGE_GLDS
+    constexpr int DMA_PER_TILE = KP / 4 + NH * (VP / 4);          // per wave
+#else
+    constexpr int DMA_PER_TILE = 0;
+#endif
+    auto ring_wait = [&](bool younger_in_flight) {
+        if constexpr (NSTAGE == 3) {
+            if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
         }
     };
     if (n_iters > 0) {
@@ -287,16 +314,21 @@ sage_attn_kernel(const AttnParams p)
         issue_loads(0, 0);
         write_lds(0);
     }
-    __syncthreads();
+    if (NSTAGE == 3 && n_iters > 1) issue_loads(1, 1);
+    ring_wait(NSTAGE == 3 && n_iters > 1);
 
+    int cur = 0;
 #pragma nounroll
     for (int it = 0; it < n_iters; it++) {
-        const int cur = it & 1;
         const bool more = (it + 1) < n_iters;
+        const bool more2 = (it + 2) < n_iters;
+        const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         float ksc_next[NH][2];
-        if (more) {
-            load_kscales(it + 1, ksc_next);
-            issue_loads(it + 1, cur ^ 1);
+        if (more) load_kscales(it + 1, ksc_next);
+        if constexpr (NSTAGE == 3) {
+            if (more2) issue_loads(it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
+        } else {
+            if (more) issue_loads(it + 1, nxt);
         }
 
         // number of 64-key halves with at least one key this wave may attend to (wave-uniform)
@@ -532,12 +564,14 @@ sage_attn_kernel(const AttnParams p)
         }
 
         if (more) {
-            write_lds(cur ^ 1);
+            write_lds(nxt);
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) { ksc[hh][0] = ksc_next[hh][0]; ksc[hh][1] = ksc_next[hh][1]; }
         }
-        __syncthreads();
+        ring_wait(more2);
+        cur = nxt;
     }
+    __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
     const float l_tot = pair_sum(l_run);
@@ -549,10 +583,26 @@ sage_attn_kernel(const AttnParams p)
     }
     // all waves are past the last tile barrier: the staging LDS is free
     unsigned char *obuf = smem + wave * (32 * D * 2);
+    // per-channel epilogue factors, fetched per 32-wide d tile as straight-line batches of 16-byte
+    // vectors (a per-element "load if non-null" makes hipcc branch around every load and wait
+    // vmcnt(0) each time: 128 serial L2 round trips per workgroup)
     const float *vsc = PV_FP8 ? p.v_scale + ((long)b * p.Hkv + hk) * D : nullptr;
     const float *vmn = (p.v_mean != nullptr) ? p.v_mean + ((long)b * p.Hkv + hk) * D : nullptr;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; dt++)
+    for (int dt = 0; dt < C::DT; dt++) {
+        v4f sc4[4], mn4[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const v4f one = {1.0f, 1.0f, 1.0f, 1.0f};
+            sc4[r4] = PV_FP8 ? *reinterpret_cast<const v4f *>(vsc + dt * 32 + 8 * r4 + 4 * g) : one;
+        }
+        if (vmn != nullptr) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) mn4[r4] = *reinterpret_cast<const v4f *>(vmn + dt * 32 + 8 * r4 + 4 * g);
+        } else {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) { const v4f z = {0.0f, 0.0f, 0.0f, 0.0f}; mn4[r4] = z; }
+        }
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
             const int d0 = dt * 32 + 8 * r4 + 4 * g;           // 4 consecutive d: regs 4*r4 .. 4*r4+3
@@ -560,8 +610,8 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 x[j] = o[dt][4 * r4 + j] * inv;
-                if (PV_FP8) x[j] *= vsc[d0 + j];
-                if (vmn != nullptr) x[j] += vmn[d0 + j];
+                if (PV_FP8) x[j] *= sc4[r4][j];
+                x[j] += mn4[r4][j];
             }
             v2u pk;
             if (p.out_dtype == DT_F16) {
@@ -575,6 +625,7 @@ sage_attn_kernel(const AttnParams p)
             const int Q = (q8 >> 1) ^ (n & 7);                 // 16-B chunk, XOR-swizzled by row
             *reinterpret_cast<v2u *>(obuf + n * (D * 2) + Q * 16 + (q8 & 1) * 8) = pk;
         }
+    }
     __syncthreads();
     {
         constexpr int LPR = D * 2 / 16;          // lanes per row (16 B each)

@@ -49,7 +49,7 @@ def qk_int8_sv_f8_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Te
         _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
         _p(value_scale), _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
-        torch.cuda.current_stream(output.device).cuda_stream)
+        torch._C._cuda_getCurrentRawStream(output.device.index))
     _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
     return lse
 
@@ -75,7 +75,7 @@ def qk_int8_sv_f16_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.T
         _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
         _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
-        torch.cuda.current_stream(output.device).cuda_stream)
+        torch._C._cuda_getCurrentRawStream(output.device.index))
     _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
     return lse
 

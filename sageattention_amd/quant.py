@@ -32,7 +32,14 @@ def _dtype_code(t: torch.Tensor) -> int:
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """Raw hipStream_t of torch's current stream on the tensor's device."""
+    return torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+
+
+# The wrappers below hand raw pointers to the C ABI; under torch.compile they must run eagerly (the
+# reference supports torch.compile in non-fullgraph mode only, README.md:30), so dynamo is told not to
+# trace into them.  The fused attention itself is a registered custom op (ops.py) and IS traceable.
+_eager = torch.compiler.disable
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -64,6 +71,7 @@ def _squeeze_km(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torc
     return km.contiguous()
 
 
+@_eager
 def _quant(x, km, blk, warp, gran, is_key, style, pre_scale, tensor_layout, nslots):
     x = _aligned(x, 8)
     B, H, L, D, sb, sh, sl = _dims(x, tensor_layout)
@@ -122,6 +130,7 @@ def _cu_blocks(cu: torch.Tensor, blk: int) -> torch.Tensor:
     return torch.nn.functional.pad(torch.cumsum((lens + blk - 1) // blk, dim=0), (1, 0), value=0).to(torch.int32)
 
 
+@_eager
 def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=None,
                           BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None):
     """Packed ``[sum L, H, D]`` per-block quantisation (quant_per_block_varlen.py:60-104).
@@ -159,6 +168,7 @@ def _stats_ws(B: int, H: int, L: int, D: int, device) -> torch.Tensor:
     return torch.empty((int(_cabi.load().sage_stats_ws_floats(B, H, L, D)),), dtype=torch.float32, device=device)
 
 
+@_eager
 def channel_mean(x: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
     """``x.mean(dim=seq)`` in the input dtype, shape ``[B, H, D]`` -- the K-smoothing mean
     (core.py:280) and the V mean of ``sub_mean`` (quant.py:216) as one deterministic HIP reduction
@@ -172,6 +182,7 @@ def channel_mean(x: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
     return out
 
 
+@_eager
 def channel_mean_packed(x: torch.Tensor) -> torch.Tensor:
     """Mean over ALL tokens of a packed ``[sum L, H, D]`` tensor -> ``[1, H, D]`` (core.py:432-434)."""
     x = _aligned(x, 8)
@@ -183,6 +194,7 @@ def channel_mean_packed(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_eager
 def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = False
                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Per-channel FP8 (e4m3fn) quantisation of V fused with the transpose into the PV tile image
@@ -202,6 +214,7 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     return v_image, v_scale, vm
 
 
+@_eager
 def prep_v_fp16(v: torch.Tensor, tensor_layout: str = "HND", vm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """FP16-PV paths: ``v.to(float16)`` (core.py:297-298,613) -- or ``(v - vm).to(float16)`` when a
     per-channel mean ``vm`` fp32 ``[B,H,D]`` is given (``sub_mean``) -- fused with the transpose into
@@ -223,6 +236,7 @@ def sub_mean(v: torch.Tensor, tensor_layout: str = "HND"):
     return prep_v_fp16(v, tensor_layout, vm=vm.float()), vm
 
 
+@_eager
 def prep_v_fp16_varlen(v: torch.Tensor, cu_seqlens_k: torch.Tensor, cu_tiles: torch.Tensor, max_seqlen_k: int) -> torch.Tensor:
     """Packed ``[sum L, H, D]`` V -> tile image ``[cu_tiles[-1], H, D, 64]`` fp16."""
     v = _aligned(v, 8)
