@@ -339,13 +339,26 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         const int8_t *qr = qp + (size_t)(r0 + i) * D;
                         const float qsc = qs[q_sidx[r0 + i]];
                         float mx = NEG_BIG;
+                        float dotf[BN], ccj[BN];
+                        /* pv_mode 0 restates the Triton kernel literally: qk = dot * (q_scale*k_scale), then
+                         * qk - m (attn_qk_int8_per_block.py:41,53-55).  The other modes restate the CUDA kernels'
+                         * update_mdo: one FMA per score, exp2(fma(s, scale, -m)) (attn_utils.cuh:445-449), with the
+                         * per-score scale formed as (q_scale * sm_scale*log2e) * k_scale. */
+                        const int fused = (pv_mode != 0) && !masked;
                         for (int j = 0; j < BN; j++) {
                             float s = NEG_BIG;
+                            dotf[j] = 0.0f; ccj[j] = 0.0f;
                             if (j < nkv && j < nk && !(causal && (n0 + j) > (r0 + i))) {
                                 const int8_t *kr = kp + (size_t)(n0 + j) * D;
                                 int32_t dot = 0;
                                 for (int d = 0; d < D; d++) dot += (int32_t)qr[d] * (int32_t)kr[d];
-                                s = (float)dot * (qsc * ks[k_sidx[n0 + j]]) * c;
+                                if (fused) {
+                                    dotf[j] = (float)dot;
+                                    ccj[j] = (qsc * c) * ks[k_sidx[n0 + j]];
+                                    s = dotf[j] * ccj[j];
+                                } else {
+                                    s = (float)dot * (qsc * ks[k_sidx[n0 + j]]) * c;
+                                }
                                 if (mask_b) s += mask_b[mo + (size_t)(r0 + i) * Lk + n0 + j] ? 0.0f : -1.0e6f;
                                 if (mask_f) s += mask_f[mo + (size_t)(r0 + i) * Lk + n0 + j];
                             } else if (masked) s = -1.0e6f;
@@ -356,7 +369,10 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         float alpha = exp2f(m[i] - m_new);
                         float rs = 0.0f;
                         for (int j = 0; j < BN; j++) {
-                            float e = (p[i][j] <= NEG_BIG) ? 0.0f : exp2f(p[i][j] - m_new);
+                            float e;
+                            if (p[i][j] <= NEG_BIG) e = 0.0f;
+                            else if (fused) e = exp2f(fmaf(dotf[j], ccj[j], -m_new));
+                            else e = exp2f(p[i][j] - m_new);
                             rs += e;
                             p[i][j] = fp8 ? orc_e4m3_2f(orc_f2e4m3(e)) : orc_h2f(orc_f2h(e));
                         }

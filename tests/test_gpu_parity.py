@@ -242,6 +242,64 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3     # q.km^T correction is rounded to fp16/bf16
 
 
+EDGE = [  # B, Hq, Hkv, Lq, Lk, D
+    (1, 1, 1, 1, 1, 64), (1, 3, 3, 5, 3, 128), (1, 6, 3, 127, 63, 64), (3, 1, 1, 129, 65, 128),
+    (1, 2, 1, 64, 64, 128), (1, 5, 5, 257, 191, 64), (2, 3, 1, 33, 1000, 128),
+]
+
+
+@pytest.mark.parametrize("shape", EDGE, ids=[f"b{a}h{b}k{c}q{d}l{e}d{f}" for a, b, c, d, e, f in EDGE])
+@pytest.mark.parametrize("pv", ["f8", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_edge_shapes_vs_oracle(oracle_mod, shape, pv, causal):
+    """Tiny / ragged / single-token / B*H not a multiple of 8 / GQA / Lq != Lk (incl. causal with Lq != Lk, which
+    the CUDA kernels allow, qk_int_sv_f16_cuda_sm80.cu:218-222, top-left aligned)."""
+    B, Hq, Hkv, Lq, Lk, D = shape
+    dt = 1 if (Lq + Lk) % 2 else 0
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=Lq * 7 + Lk, kbias=1.0)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    fn = sa.sageattn_qk_int8_pv_fp8_cuda if pv == "f8" else sa.sageattn_qk_int8_pv_fp16_cuda
+    o, lse = fn(qd, kd, vd, is_causal=causal, pv_accum_dtype="fp32+fp32" if pv == "f8" else "fp32", return_lse=True)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean(kd))
+    ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv=pv,
+                                                qk_quant_gran="per_thread", return_lse=True, km=km)
+    got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
+    assert np.isfinite(got).all()
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
+
+
+def test_strided_views_of_a_packed_qkv_tensor():
+    """q/k/v as non-contiguous views (the usual fused-QKV projection output): strides are honoured, no copies."""
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(2, 300, 3, 8, 128, generator=g).half().to(DEV)          # [B, L, 3, H, D]
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                          # NHD views, stride(1) = 3*H*D
+    o = sa.sageattn(q, k, v, tensor_layout="NHD", is_causal=True)
+    o_ref = sa.sageattn(q.contiguous(), k.contiguous(), v.contiguous(), tensor_layout="NHD", is_causal=True)
+    torch.cuda.synchronize()
+    assert o.shape == q.shape and torch.equal(o, o_ref)
+    oh = sa.sageattn(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), tensor_layout="HND", is_causal=True)
+    assert torch.equal(oh.transpose(1, 2), o_ref)
+
+
+def test_long_sequence_32k_vs_oracle(oracle_mod):
+    """N = 32768 (the longest point of the published sweep), one GQA group, against the CPU oracle."""
+    q, k, v = rand_qkv(1, 2, 1, 32768, 32768, 128, 1, seed=77, kbias=1.0)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = sa.sageattn(qd, kd, vd, is_causal=True)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean(kd))
+    ref, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 1, is_causal=True, pv="f8",
+                                          qk_quant_gran="per_thread", km=km)
+    got, ref = o.float().cpu().numpy(), util.f32(ref, 1)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    REPORT["kernel_vs_oracle/n32768_causal_f8"] = dict(max_abs=err, max_o=scale)
+    assert err <= 2e-3 * scale + 2 ** -8 * scale
+
+
 # ------------------------------------------------------------------------------------------------ golden (reference outputs)
 @pytest.mark.parametrize("name", ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16",
                                   "causal_n384d128_f16", "pad_d96_n160_f16"])
