@@ -40,6 +40,8 @@ CONFIGS = {
                workload="qk_int8_pv_fp16 B=2 H=32 N=4096 D=128 causal (BASELINE.json configs[1])"),
     "c3": dict(B=2, H=32, Hkv=32, N=8192, D=128, causal=True, pv="fp8", dtype="bf16",
                workload="qk_int8_pv_fp8 two-level accum B=2 H=32 N=8192 D=128 causal (BASELINE.json configs[2])"),
+    "c3nc": dict(B=2, H=32, Hkv=32, N=8192, D=128, causal=False, pv="fp8", dtype="bf16",
+                 workload="qk_int8_pv_fp8 two-level accum B=2 H=32 N=8192 D=128 NON-causal (balance probe)"),
     "c5": dict(B=2, H=48, Hkv=48, N=17776, D=64, causal=False, pv="fp8", dtype="bf16",
                workload="CogVideoX1.5-5B shaped sageattn() B=2 H=48 N=17776 D=64 non-causal (BASELINE.json configs[4])"),
 }

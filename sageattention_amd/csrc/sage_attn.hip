@@ -94,7 +94,18 @@ sage_attn_kernel(const AttnParams p)
     }
     const int nqblk = p.nqblk;
     const int bh = wid / nqblk;
+#ifndef SAGE_ORDER
+#define SAGE_ORDER 0
+#endif
+#if SAGE_ORDER == 0
     const int qblk = nqblk - 1 - (wid - bh * nqblk);   // longest (causal) blocks first
+#elif SAGE_ORDER == 1
+    const int qblk = wid - bh * nqblk;                 // experiment: shortest first
+#else
+    // experiment: alternate long / short blocks (0, n-1, 1, n-2, ...)
+    const int r_ = wid - bh * nqblk;
+    const int qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));
+#endif
     const int b = bh / p.Hq;
     const int h = bh - b * p.Hq;
     const int hk = h / p.group;

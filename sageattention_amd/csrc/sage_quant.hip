@@ -129,9 +129,19 @@ quant_int8_kernel(const QuantParams p)
         } else {
             float sc = am / 127.0f;
             if (p.style == QS_TRITON_THREAD) sc += 1e-7f;
+            // x / scale must be the correctly rounded IEEE quotient (the reference divides, quant_per_block.py:41;
+            // the +-0.5 / truncate that follows makes a 1-ulp error visible in the int8).  One IEEE reciprocal per
+            // chunk, then per element the FMA-based Markstein refinement q <- q + (x - scale*q) * y, twice: the
+            // first step makes q faithful, the second makes it the correctly rounded quotient (operands are far
+            // from overflow/underflow: |x| <= 127.5 * scale).  5 full-rate VALU ops instead of the compiler's
+            // ~10-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence per element.
+            const float y = (sc == 0.0f) ? 0.0f : 1.0f / sc;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                float t = (sc == 0.0f) ? 0.0f : v[i][j] / sc;        // quant_per_block.py:41-45
+                const float x = v[i][j];
+                float t = x * y;
+                t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
+                t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
                 t += (t >= 0.0f) ? 0.5f : -0.5f;
                 int qi = (int)t;                                     // truncation toward zero
                 qi = qi > 127 ? 127 : (qi < -128 ? -128 : qi);

@@ -106,6 +106,36 @@ def test_quant_int8_bit_exact(oracle_mod, gran, dt, D, layout):
         assert (a == b).all(), f"{name}: {(a != b).sum()} mismatches of {a.size}"
 
 
+@pytest.mark.parametrize("style", ["triton", "thread"])
+def test_quant_division_is_correctly_rounded_stress(oracle_mod, style):
+    """The quantiser replaces x/scale by a reciprocal + two FMA refinements; it must stay bit-exact with true IEEE
+    division, including values parked right on the +-0.5 rounding boundaries (x = (k + 0.5) * scale +- 1 ulp)."""
+    g = torch.Generator().manual_seed(99)
+    B, H, L, D = 2, 8, 2048, 128
+    x = torch.randn(B, H, L, D, generator=g) * (1.0 + 10.0 * torch.rand(B, H, 1, 1, generator=g))
+    # adversarial rows: multiples of amax/127 offset by half a step, nudged by one fp16 ulp either way
+    amax = x.abs().amax(dim=(2, 3), keepdim=True)
+    kk = torch.randint(-127, 127, (B, H, L // 4, D), generator=g).float()
+    x[:, :, : L // 4] = (kk + 0.5) * (amax / 127.0)
+    x = x.half()
+    x[:, :, : L // 8] = torch.nextafter(x[:, :, : L // 8], torch.full_like(x[:, :, : L // 8], 1e4))
+    xd = x.to(DEV)
+    if style == "triton":
+        q8, qs, k8, ks = sq.per_block_int8(xd, xd, sm_scale=1.0 / sq.LOG2E)
+        gq, nq = oracle_mod.group_index(L, "per_block", "q", 128, 128); gk, nk = oracle_mod.group_index(L, "per_block", "k", 64, 64)
+        rq8, rqs = oracle_mod.quant_int8(util.bits(x), 0, gq, nq, pre_scale=np.float32((1.0 / sq.LOG2E) * oracle_mod.LOG2E), style=oracle_mod.STYLE_TRITON)
+        rk8, rks = oracle_mod.quant_int8(util.bits(x), 0, gk, nk, style=oracle_mod.STYLE_TRITON)
+    else:
+        q8, qs, k8, ks = sq.per_thread_int8(xd, xd)
+        gq, nq = oracle_mod.group_index(L, "per_thread", "q", 128, 32); gk, nk = oracle_mod.group_index(L, "per_thread", "k", 64, 64)
+        rq8, rqs = oracle_mod.quant_int8(util.bits(x), 0, gq, nq, style=oracle_mod.STYLE_TRITON_THREAD)
+        rk8, rks = oracle_mod.quant_int8(util.bits(x), 0, gk, nk, style=oracle_mod.STYLE_TRITON_THREAD)
+    torch.cuda.synchronize()
+    assert (qs.cpu().numpy() == rqs).all() and (ks.cpu().numpy() == rks).all()
+    assert (q8.cpu().numpy() == rq8).all(), f"{(q8.cpu().numpy() != rq8).sum()} q mismatches"
+    assert (k8.cpu().numpy() == rk8).all(), f"{(k8.cpu().numpy() != rk8).sum()} k mismatches"
+
+
 def test_quant_golden_per_thread(oracle_mod):
     """Bit-exact against the reference's own per-thread quantiser output (fixture)."""
     z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden("per_thread_quant_d128_f16")
