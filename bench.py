@@ -171,12 +171,38 @@ def accuracy(cfg, q, k, v):
             "rel_rmse_vs_fp32_sdpa": round(util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean())), 5)}
 
 
+C4_LENS = [256, 512, 1000, 1024, 2048, 4096, 8192, 16384]     # SURVEY.md 8d, BASELINE.json configs[3]
+
+
+def run_c4(args, device):
+    """sageattn_varlen, GQA Hq=32 Hkv=8 D=128 bf16, mixed lengths: whole-call throughput (the reference has no
+    kernel-only benchmark for the varlen path)."""
+    import sageattention_amd as sa
+    g = torch.Generator(device="cpu").manual_seed(4)
+    total = sum(C4_LENS)
+    q = torch.randn(total, 32, 128, generator=g).to(torch.bfloat16).to(device)
+    k = torch.randn(total, 8, 128, generator=g).to(torch.bfloat16).to(device)
+    v = torch.randn(total, 8, 128, generator=g).to(torch.bfloat16).to(device)
+    cu = torch.tensor([0] + list(torch.tensor(C4_LENS).cumsum(0)), dtype=torch.int32, device=device)
+    out = {}
+    for causal in (False, True):
+        fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(C4_LENS), max(C4_LENS), is_causal=causal)
+        wall, dev_ms = timed(fn, args.steps, args.warmup, False)
+        fl = sum(4.0 * 32 * L * L * 128 for L in C4_LENS) / (2 if causal else 1)
+        out["causal" if causal else "non_causal"] = {"ms_per_call": round(wall / args.steps * 1e3, 4),
+                                                     "tflops": round(fl / (wall / args.steps) / 1e12, 2)}
+    print(json.dumps({"metric": "sageattn_varlen end-to-end TFLOPS (INT8 QK^T + FP16 PV)", "unit": "TFLOP/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "value": out["causal"]["tflops"], "higher_is_better": True,
+                      "config": {"workload": "sageattn_varlen GQA Hq=32 Hkv=8 D=128 bf16, lengths " + str(C4_LENS) + " (BASELINE.json configs[3])"},
+                      "detail": out, "data": "synthetic"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--sweep", action="store_true", help="also print hd128 causal N=1k..32k kernel-only TFLOPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -197,6 +223,9 @@ def main():
     from sageattention_amd import _cabi
     _cabi.load()
 
+    if args.config == "c4":
+        run_c4(args, device)
+        return
     cfg = CONFIGS[args.config]
     # weak scaling: every rank owns B*H (batch, kv-head) units of the global batch (B*world)
     q, k, v = make_inputs(cfg, device, seed=1234 + rank)
