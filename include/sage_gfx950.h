@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 3
+#define SAGE_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -202,11 +202,13 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
 
 /* Variable-length fused attention (per-block scales, FP16 PV), packed q/o [sum Lq, Hq, D],
  * k [sum Lk, Hkv, D].  Replaces: attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125.
- * cu_q_scale / cu_k_scale: prefix sums of ceil(Lq_i/128) / ceil(Lk_i/64) (also the V tile prefix). */
+ * cu_q_scale / cu_k_scale: prefix sums of ceil(Lq_i/128) / ceil(Lk_i/64) (also the V tile prefix).
+ * seq_order (nullable, device int32[nseq]): a permutation of the sequence indices giving the order in which the
+ * launch schedules them -- longest first shortens the tail; results do not depend on it. */
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
                                     const float *q_scale, const float *k_scale,
                                     const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
-                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale,
+                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale, const int32_t *seq_order,
                                     int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh,
                                     int64_t o_sl, int64_t o_sh,

@@ -197,9 +197,11 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k)
     o = torch.empty(q.shape, dtype=dtype, device=q.device)
     code = _cabi.DTYPE_F16 if dtype == torch.float16 else _cabi.DTYPE_BF16
+    # schedule the longest sequences first (device-side sort, no sync); results do not depend on the order
+    order = torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
     rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
         _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(q_scale), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_qs), _p(cu_ks),
-        cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),
+        _p(order), cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),
         o.stride(0), o.stride(1), int(is_causal), 1.0, _cabi.PV_ACCUM_TWO_LEVEL, code, _stream(o))
     _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
     return o[..., :head_dim_og]

@@ -83,32 +83,47 @@ sage_attn_kernel(const AttnParams p)
     const int g = lane >> 5;      // k-group (operand half)
 
     // ---- work item: XCD-aware, heavy-first --------------------------------------------------
-    // blocks b, b+8, b+16.. share an XCD (b % 8); give each XCD a contiguous run of work items
-    // so that the q-blocks of one (batch, kv-head) hit the same L2.
-    const int nwg = gridDim.x;
-    int wid;
-    {
+    const int nqblk = p.nqblk;
+    int b, h, hk, qblk;
+    if (p.cu_q != nullptr) {
+        // varlen: sequences differ in length, so a contiguous run per XCD would hand one XCD the longest sequence
+        // (measured 3.5x slower on lengths 256..16384).  XCDs take (sequence, kv-head) units round-robin instead;
+        // inside a unit the `group` query heads that share the K/V stream run heavy-first, interleaved.
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int per_unit = nqblk * p.group;
+        const int j = idx / per_unit, within = idx - j * per_unit;
+        const int u = j * 8 + xcd;
+        if (u >= p.B * p.Hkv) return;
+        const int r = within / p.group, hg = within - r * p.group;
+        qblk = nqblk - 1 - r;
+        const int bs = u / p.Hkv;
+        hk = u - bs * p.Hkv;
+        b = p.seq_order != nullptr ? p.seq_order[bs] : bs;      // caller's processing order (longest first)
+        h = hk * p.group + hg;
+    } else {
+        // blocks b, b+8, b+16.. share an XCD (b % 8); give each XCD a contiguous run of work items
+        // so that the q-blocks of one (batch, kv-head) hit the same L2.
+        const int nwg = gridDim.x;
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
         const int qq = nwg >> 3, rr = nwg & 7;
-        wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
-    const int nqblk = p.nqblk;
-    const int bh = wid / nqblk;
+        const int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        const int bh = wid / nqblk;
 #ifndef SAGE_ORDER
 #define SAGE_ORDER 0
 #endif
 #if SAGE_ORDER == 0
-    const int qblk = nqblk - 1 - (wid - bh * nqblk);   // longest (causal) blocks first
+        qblk = nqblk - 1 - (wid - bh * nqblk);   // longest (causal) blocks first
 #elif SAGE_ORDER == 1
-    const int qblk = wid - bh * nqblk;                 // experiment: shortest first
+        qblk = wid - bh * nqblk;                 // experiment: shortest first
 #else
-    // experiment: alternate long / short blocks (0, n-1, 1, n-2, ...)
-    const int r_ = wid - bh * nqblk;
-    const int qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));
+        // experiment: alternate long / short blocks (0, n-1, 1, n-2, ...)
+        const int r_ = wid - bh * nqblk;
+        qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));
 #endif
-    const int b = bh / p.Hq;
-    const int h = bh - b * p.Hq;
-    const int hk = h / p.group;
+        b = bh / p.Hq;
+        h = bh - b * p.Hq;
+        hk = h / p.group;
+    }
 
     // ---- per-sequence geometry ---------------------------------------------------------------
     int Lq = p.Lq, Lk = p.Lk;
@@ -695,7 +710,8 @@ static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stre
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
                        bool two_level, int mask_kind, hipStream_t stream)
 {
-    const int nwork = p.B * p.Hq * p.nqblk;
+    // varlen grids are padded to whole rounds of 8 (sequence, kv-head) units, see the work-item mapping
+    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
         if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)

@@ -39,7 +39,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 int64_t o_sb, int64_t o_sh, int64_t o_sl,
                 int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream,
-                const MaskArg *mask = nullptr)
+                const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr)
 {
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -58,7 +58,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     sage::AttnParams p{};
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
-    p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks;
+    p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
     p.Lq = Lq; p.Lk = Lk;
     p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
@@ -285,7 +285,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
                                     const float *q_scale, const float *k_scale,
                                     const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
-                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale,
+                                    const int32_t *cu_q_scale, const int32_t *cu_k_scale, const int32_t *seq_order,
                                     int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
                                     int is_causal, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
@@ -293,7 +293,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
     return attn_common(false, true, q, k, v_image, o, nullptr, q_scale, k_scale, nullptr, nullptr,
                        cu_seqlens_q, cu_seqlens_k, cu_q_scale, cu_k_scale,
                        nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
-                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream);
+                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ struct AttnParams {
     const int32_t *cu_k;
     const int32_t *cu_qs;     // prefix sums of ceil(Lq_i/128)
     const int32_t *cu_ks;     // prefix sums of ceil(Lk_i/64)
+    const int32_t *seq_order; // varlen, nullable: permutation of sequence indices in processing order
     int B, Hq, Hkv, group;    // group = Hq / Hkv
     int Lq, Lk;               // dense lengths; varlen: max lengths (grid sizing only)
     int nqblk;                // ceil(max Lq / 128)

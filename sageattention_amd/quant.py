@@ -75,7 +75,11 @@ def _squeeze_km(km: Optional[torch.Tensor], tensor_layout: str) -> Optional[torc
 def _quant(x, km, blk, warp, gran, is_key, style, pre_scale, tensor_layout, nslots):
     x = _aligned(x, 8)
     B, H, L, D, sb, sh, sl = _dims(x, tensor_layout)
-    out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    # INT8 rows are stored head-major ([B, H, L, D] in memory) whatever the logical layout: the attention kernel
+    # streams 64-row K tiles, and rows H*D bytes apart land on a fraction of the L2 channels (measured 3.5x slower)
+    out = torch.empty((B, H, L, D), dtype=torch.int8, device=x.device)
+    if tensor_layout == "NHD":
+        out = out.permute(0, 2, 1, 3)
     _, _, _, _, ob, oh, ol = _dims(out, tensor_layout)
     scale = torch.empty((B, H, ((L + blk - 1) // blk) * nslots), dtype=torch.float32, device=x.device)
     if km is not None:
@@ -144,8 +148,9 @@ def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_se
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
     cu_qs, cu_ks = _cu_blocks(cu_q, BLKQ), _cu_blocks(cu_k, BLKK)
-    q_int8 = torch.empty(q.shape, dtype=torch.int8, device=q.device)
-    k_int8 = torch.empty(k.shape, dtype=torch.int8, device=k.device)
+    # head-major storage behind the packed [sum L, H, D] view (see _quant)
+    q_int8 = torch.empty((Hq, q.shape[0], D), dtype=torch.int8, device=q.device).permute(1, 0, 2)
+    k_int8 = torch.empty((Hkv, k.shape[0], D), dtype=torch.int8, device=k.device).permute(1, 0, 2)
     # one host sync, as in the reference (`torch.empty((cu_seqlens_q_scale[-1], h_qo))`, :75)
     nq, nk = int(cu_qs[-1].item()), int(cu_ks[-1].item())
     q_scale = torch.empty((nq, Hq), dtype=torch.float32, device=q.device)
