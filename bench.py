@@ -44,6 +44,10 @@ CONFIGS = {
                  workload="qk_int8_pv_fp8 two-level accum B=2 H=32 N=8192 D=128 NON-causal (balance probe)"),
     "c5": dict(B=2, H=48, Hkv=48, N=17776, D=64, causal=False, pv="fp8", dtype="bf16",
                workload="CogVideoX1.5-5B shaped sageattn() B=2 H=48 N=17776 D=64 non-causal (BASELINE.json configs[4])"),
+    # XCD balance probes (head counts that are not multiples of 8)
+    "h28": dict(B=1, H=28, Hkv=4, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=28 Hkv=4 N=8192 causal"),
+    "h12": dict(B=1, H=12, Hkv=12, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=12 N=8192 causal"),
+    "h4": dict(B=1, H=4, Hkv=4, N=16384, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=4 N=16384 causal"),
 }
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, fp8 5.0 PF (the MX-scaled
 # instruction the PV step issues; the non-scaled fp8 MFMA runs at the bf16 rate), int8 = 2x bf16 = 5.0 POPS.

@@ -101,24 +101,47 @@ sage_attn_kernel(const AttnParams p)
         b = p.seq_order != nullptr ? p.seq_order[bs] : bs;      // caller's processing order (longest first)
         h = hk * p.group + hg;
     } else {
-        // blocks b, b+8, b+16.. share an XCD (b % 8); give each XCD a contiguous run of work items
-        // so that the q-blocks of one (batch, kv-head) hit the same L2.
-        const int nwg = gridDim.x;
+        // workgroups bid, bid+8, bid+16.. share an XCD (bid % 8); each XCD takes one contiguous run of work items,
+        // so the q-blocks of one head -- and the query heads of one GQA group -- stream K/V through one L2.
+        // SAGE_XCD_MAP=1 (experiment): whole heads dealt in rounds of 8, left-over heads q-block by q-block.  Better
+        // balanced for causal head counts that are not multiples of 8, but it spreads a GQA group / a long head's
+        // K/V over all eight L2s and measured 6-14 % slower there (profiles/r1_run28_xcd_map.txt).
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int nbh = p.B * p.Hq;
+#ifndef SAGE_XCD_MAP
+#define SAGE_XCD_MAP 0
+#endif
+#if SAGE_XCD_MAP == 1
+        const int full = (nbh >> 3) * nqblk;          // work items per XCD from whole rounds
+        int bh, r_;
+        if (idx < full) {
+            const int rd = idx / nqblk;
+            bh = rd * 8 + xcd;
+            r_ = idx - rd * nqblk;
+        } else {
+            const int gidx = (idx - full) * 8 + xcd;  // interleaved over the left-over heads
+            const int hh = gidx / nqblk;
+            bh = (nbh & ~7) + hh;
+            if (bh >= nbh) return;
+            r_ = gidx - hh * nqblk;
+        }
+#else
+        const int nwg = gridDim.x;
         const int qq = nwg >> 3, rr = nwg & 7;
         const int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
         const int bh = wid / nqblk;
+        const int r_ = wid - bh * nqblk;
+        if (bh >= nbh) return;
+#endif
 #ifndef SAGE_ORDER
 #define SAGE_ORDER 0
 #endif
 #if SAGE_ORDER == 0
-        qblk = nqblk - 1 - (wid - bh * nqblk);   // longest (causal) blocks first
+        qblk = nqblk - 1 - r_;                   // longest (causal) blocks first
 #elif SAGE_ORDER == 1
-        qblk = wid - bh * nqblk;                 // experiment: shortest first
+        qblk = r_;                               // experiment: shortest first
 #else
-        // experiment: alternate long / short blocks (0, n-1, 1, n-2, ...)
-        const int r_ = wid - bh * nqblk;
-        qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));
+        qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));   // experiment: alternate long / short
 #endif
         b = bh / p.Hq;
         h = bh - b * p.Hq;
@@ -711,7 +734,13 @@ hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool caus
                        bool two_level, int mask_kind, hipStream_t stream)
 {
     // varlen grids are padded to whole rounds of 8 (sequence, kv-head) units, see the work-item mapping
-    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : p.B * p.Hq * p.nqblk;
+    const int nbh = p.B * p.Hq;
+#if defined(SAGE_XCD_MAP) && SAGE_XCD_MAP == 1
+    const int dense_work = (nbh / 8) * 8 * p.nqblk + (((nbh % 8) * p.nqblk + 7) / 8) * 8;
+#else
+    const int dense_work = nbh * p.nqblk;
+#endif
+    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : dense_work;
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
         if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)
