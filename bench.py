@@ -254,7 +254,7 @@ def main():
     peak = blended_peak(cfg["pv"])
 
     out = {
-        "metric": "attention TFLOPS (causal, hd=128), kernel-only, as published by the reference",
+        "metric": "attention TFLOPS (%s, hd=%d), kernel-only, as published by the reference" % ("causal" if cfg["causal"] else "non-causal", cfg["D"]),
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / world / 795.0, 4) if args.config == "c3" else None,
