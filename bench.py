@@ -47,6 +47,8 @@ CONFIGS = {
     # XCD balance probes (head counts that are not multiples of 8)
     "h28": dict(B=1, H=28, Hkv=4, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=28 Hkv=4 N=8192 causal"),
     "h12": dict(B=1, H=12, Hkv=12, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=12 N=8192 causal"),
+    "d64f16": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp16", dtype="fp16", workload="probe D=64 FP16 PV B=2 H=32 N=8192 causal"),
+    "d64f8": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp8", dtype="bf16", workload="probe D=64 FP8 PV B=2 H=32 N=8192 causal"),
     "h4": dict(B=1, H=4, Hkv=4, N=16384, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=4 N=16384 causal"),
 }
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, fp8 5.0 PF (the MX-scaled

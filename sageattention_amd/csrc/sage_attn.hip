@@ -37,6 +37,12 @@
 #ifndef SAGE_MXPV       // FP8 PV on the block-scaled K=64 MFMA with unit scales (+5%)
 #define SAGE_MXPV 1
 #endif
+#ifndef SAGE_PV2BUF     // two PV tile accumulators in flight (fold of d-tile dt overlaps the MFMA of dt+1)
+#define SAGE_PV2BUF 0
+#endif
+#ifndef SAGE_STEADY     // branch-free steady-state iteration for whole, unmasked tiles
+#define SAGE_STEADY 1
+#endif
 #ifndef SAGE_STAGES     // LDS ring depth: 3 = two tiles in flight, counted vmcnt + raw s_barrier (needs SAGE_GLDS)
 #define SAGE_STAGES 3
 #endif
@@ -232,11 +238,11 @@ sage_attn_kernel(const AttnParams p)
         const int row = e / CPR, phys = e % CPR;
         koff[i] = (unsigned)(row * (int)p.k_sl + swz_chunk<D>(row, phys) * 16);
     }
-    auto issue_loads = [&](int it, int buf) {
+    auto issue_loads = [&](auto steady_tag, int it, int buf) {      // steady: tile `it` is known to be a whole tile
         unsigned char *ks = smem + buf * C::STAGE_BYTES;
         unsigned char *vs = ks + C::K_TILE_BYTES;
         const unsigned char *kt = kbase + (long)it * KT * p.k_sl;
-        if (it * KT + KT <= Lk) {
+        if (decltype(steady_tag)::value || it * KT + KT <= Lk) {
 #pragma unroll
             for (int i = 0; i < KP / 4; i++) {
                 const int pc = wave * (KP / 4) + i;
@@ -259,7 +265,7 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             int tv = it * NH + hh;
-            tv = tv < ntk_all ? tv : ntk_all - 1;
+            if (!decltype(steady_tag)::value) tv = tv < ntk_all ? tv : ntk_all - 1;
             const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
 #pragma unroll
             for (int i = 0; i < VP / 4; i++) {
@@ -273,7 +279,7 @@ sage_attn_kernel(const AttnParams p)
 #else
     constexpr int K_LD = C::K_TILE_BYTES / 4096, V_LD = C::V_IMG_BYTES / 4096;
     v4u kreg[K_LD], vreg[NH][V_LD];
-    auto issue_loads = [&](int it, int) {
+    auto issue_loads = [&](auto, int it, int) {
 #pragma unroll
         for (int i = 0; i < K_LD; i++) {
             const int piece = tid * K_LD + i;
@@ -353,39 +359,44 @@ sage_attn_kernel(const AttnParams p)
         if constexpr (NSTAGE == 3) {
             if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef SAGE_EXP_NOBAR          // timing probe only (results are wrong without the barrier)
             __builtin_amdgcn_s_barrier();
+#endif
         } else {
             __syncthreads();
         }
     };
     if (n_iters > 0) {
         load_kscales(0, ksc);
-        issue_loads(0, 0);
+        issue_loads(std::false_type{}, 0, 0);
         write_lds(0);
     }
-    if (NSTAGE == 3 && n_iters > 1) issue_loads(1, 1);
+    if (NSTAGE == 3 && n_iters > 1) issue_loads(std::false_type{}, 1, 1);
     ring_wait(NSTAGE == 3 && n_iters > 1);
 
     int cur = 0;
-#pragma nounroll
-    for (int it = 0; it < n_iters; it++) {
-        const bool more = (it + 1) < n_iters;
-        const bool more2 = (it + 2) < n_iters;
+    // One K/V tile.  STEADY = the tile is whole and unmasked for every wave of the workgroup and tiles it+1, it+2
+    // exist and are whole: all wave-uniform conditionals of the general form fold away (the general iteration
+    // spends 14 scalar branches per tile on them).
+    auto tile_iter = [&](auto steady_tag, const int it) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const bool more = STEADY || (it + 1) < n_iters;
+        const bool more2 = STEADY || (it + 2) < n_iters;
         const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         float ksc_next[NH][2];
         if (more) load_kscales(it + 1, ksc_next);
         if constexpr (NSTAGE == 3) {
-            if (more2) issue_loads(it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
+            if (more2) issue_loads(steady_tag, it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
         } else {
-            if (more) issue_loads(it + 1, nxt);
+            if (more) issue_loads(std::false_type{}, it + 1, nxt);
         }
 
         // number of 64-key halves with at least one key this wave may attend to (wave-uniform)
-        int nact = 0;
+        int nact = STEADY ? NH : 0;
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             const int key0 = it * KT + hh * BLKK;
-            if (key0 < Lk && (!CAUSAL || key0 <= row0 + 31)) nact = hh + 1;
+            if (!STEADY && key0 < Lk && (!CAUSAL || key0 <= row0 + 31)) nact = hh + 1;
         }
         // ---- attn_mask (Triton-named API only; attn_qk_int8_per_block.py:31-51): additive term per
         //      score in the log2 domain.  bool: 0 / -1e6, and a tile whose whole 128x64 mask block is
@@ -413,11 +424,11 @@ sage_attn_kernel(const AttnParams p)
                 }
             if (MASK == 1) skip_tile = !__syncthreads_or(anytrue);
         }
-        if (nact > 0 && !skip_tile) {
+        if (STEADY || (nact > 0 && !skip_tile)) {
             const unsigned char *ks = smem + cur * C::STAGE_BYTES;
             const unsigned char *vs = ks + C::K_TILE_BYTES;
             const int last_key = it * KT + nact * BLKK - 1;
-            const bool full = (MASK == 0) && (nact == NH) && !(CAUSAL && last_key > row0) && (last_key < Lk);
+            const bool full = STEADY || ((MASK == 0) && (nact == NH) && !(CAUSAL && last_key > row0) && (last_key < Lk));
 
             // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
             v16i s[NS];
@@ -425,7 +436,7 @@ sage_attn_kernel(const AttnParams p)
             for (int sb = 0; sb < NS; sb++) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) s[sb][i] = 0;
-                if (sb < 2 * nact) {
+                if (STEADY || sb < 2 * nact) {
                     const int krow = sb * 32 + n;
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
@@ -535,6 +546,34 @@ sage_attn_kernel(const AttnParams p)
                 if (full) build_p(std::false_type{});
                 else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;      // lane-partial; the pair is summed in the epilogue
+#if SAGE_PV2BUF && SAGE_MXPV
+                if constexpr (TWO_LEVEL && NH == 1) {
+                    // Two tile accumulators in flight: the O = O*alpha + T fold of d-tile dt runs on the VALU while
+                    // the MFMA of d-tile dt+1 is still in the matrix pipe (hipcc otherwise reuses one accumulator
+                    // and serialises MFMA -> wait -> 8 packed FMAs four times per tile).
+                    const v8i bv = {pw[0][0], pw[0][1], pw[0][2], pw[0][3], pw[0][4], pw[0][5], pw[0][6], pw[0][7]};
+                    auto pv_tile = [&](int dt) -> v16f {
+                        const int drow = dt * 32 + n;
+                        const unsigned char *vr = vs + drow * 64;
+                        const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
+                        const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
+                        const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
+                        v16f z;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) z[i] = 0.0f;
+                        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, z, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    };
+                    v16f t0 = pv_tile(0);
+                    v16f t1 = pv_tile(1);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; dt++) {
+                        v16f &t = (dt & 1) ? t1 : t0;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, t[i]);
+                        if (dt + 2 < C::DT) t = pv_tile(dt + 2);
+                    }
+                } else
+#endif
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) {
                     const int drow = dt * 32 + n;
@@ -545,7 +584,7 @@ sage_attn_kernel(const AttnParams p)
                     } else acc = o[dt];
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++) {
-                        if (hh < nact) {
+                        if (STEADY || hh < nact) {
                             const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
                             const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
                             const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
@@ -595,7 +634,7 @@ sage_attn_kernel(const AttnParams p)
                     } else acc = o[dt];
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++) {
-                        if (hh < nact) {
+                        if (STEADY || hh < nact) {
                             const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
@@ -619,7 +658,20 @@ sage_attn_kernel(const AttnParams p)
         }
         ring_wait(more2);
         cur = nxt;
+    };
+    int it = 0;
+#if SAGE_STEADY
+    if constexpr (MASK == 0 && NH == 1 && NSTAGE == 3) {
+        // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
+        int n_steady = Lk / KT - 2;
+        n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
+        if (CAUSAL) n_steady = n_steady < 2 * qblk ? n_steady : 2 * qblk;
+#pragma nounroll
+        for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
     }
+#endif
+#pragma nounroll
+    for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
