@@ -108,10 +108,20 @@ def e2e_step(cfg, q, k, v):
     return sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=cfg["causal"], pv_accum_dtype="fp32")
 
 
-def timed(fn, steps, warmup, dist_on):
+def timed(fn, steps, warmup, dist_on, ramp_s=0.0):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides; also per-step HIP
-    event durations (events recorded on the stream the kernels are launched on = torch's current)."""
+    event durations (events recorded on the stream the kernels are launched on = torch's current).
+    ramp_s: untimed pre-phase that keeps the device busy with the same step for that many seconds.  An idle
+    MI355X needs ~40-50 ms of continuous work to reach its sustained clocks (tools/dvfs_probe.py,
+    profiles/r1_run40_dvfs.txt: launch 0 = 1139 us, launches 50..400 = 808-816 us); without it a short run
+    times the ramp instead of the steady state."""
     import torch.distributed as dist
+    if ramp_s > 0:
+        t_end = time.perf_counter() + ramp_s
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -193,7 +203,7 @@ def run_c4(args, device):
     out = {}
     for causal in (False, True):
         fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(C4_LENS), max(C4_LENS), is_causal=causal)
-        wall, dev_ms = timed(fn, args.steps, args.warmup, False)
+        wall, dev_ms = timed(fn, args.steps, args.warmup, False, args.ramp_seconds)
         fl = sum(4.0 * 32 * L * L * 128 for L in C4_LENS) / (2 if causal else 1)
         out["causal" if causal else "non_causal"] = {"ms_per_call": round(wall / args.steps * 1e3, 4),
                                                      "tflops": round(fl / (wall / args.steps) / 1e12, 2)}
@@ -206,8 +216,10 @@ def run_c4(args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-seconds", type=float, default=0.3,
+                    help="untimed clock-ramp phase before the warmup steps (0 disables); reported in the JSON")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--sweep", action="store_true", help="also print hd128 causal N=1k..32k kernel-only TFLOPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,8 +251,8 @@ def main():
     ops = prequantize(cfg, q, k, v)
     torch.cuda.synchronize()
 
-    wall_k, dev_k = timed(lambda: kernel_only_step(cfg, ops, sm_scale), args.steps, args.warmup, dist_on)
-    wall_e, dev_e = timed(lambda: e2e_step(cfg, q, k, v), max(3, args.steps // 2), 2, dist_on)
+    wall_k, dev_k = timed(lambda: kernel_only_step(cfg, ops, sm_scale), args.steps, args.warmup, dist_on, args.ramp_seconds)
+    wall_e, dev_e = timed(lambda: e2e_step(cfg, q, k, v), max(3, args.steps // 2), 2, dist_on, args.ramp_seconds)
     e2e_steps = max(3, args.steps // 2)
 
     stats = torch.tensor([wall_k, wall_e], dtype=torch.float64, device=device)
@@ -259,6 +271,7 @@ def main():
         "metric": "attention TFLOPS (%s, hd=%d), kernel-only, as published by the reference" % ("causal" if cfg["causal"] else "non-causal", cfg["D"]),
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "clock_ramp_seconds": args.ramp_seconds,
         "vs_baseline": round(value / world / 795.0, 4) if args.config == "c3" else None,
         "vs_baseline_note": "per-GPU kernel-only TFLOPS / 795 (SageAttn2-8b, H100, hd128 causal N=8k; BASELINE.md section 1)",
         "dtype": "int8 QK^T + " + ("fp8(e4m3) PV" if cfg["pv"] == "fp8" else "fp16 PV") + ", fp32 accumulate",
@@ -287,7 +300,7 @@ def main():
                 c = dict(cfg, N=n)
                 qq, kk, vv = make_inputs(c, device, seed=n)
                 oo = prequantize(c, qq, kk, vv)
-                _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 10, 3, False)
+                _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 20, 5, False, min(args.ramp_seconds, 0.2))
                 sweep[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
                 del qq, kk, vv, oo
             out["sweep_kernel_only_tflops"] = sweep

@@ -40,6 +40,9 @@
 #ifndef SAGE_PV2BUF     // two PV tile accumulators in flight (fold of d-tile dt overlaps the MFMA of dt+1)
 #define SAGE_PV2BUF 0
 #endif
+#ifndef SAGE_KPRELOAD   // steady iteration: request all K fragments before the first QK MFMA
+#define SAGE_KPRELOAD 1
+#endif
 #ifndef SAGE_STEADY     // branch-free steady-state iteration for whole, unmasked tiles
 #define SAGE_STEADY 1
 #endif
@@ -432,6 +435,31 @@ sage_attn_kernel(const AttnParams p)
 
             // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
             v16i s[NS];
+#if SAGE_KPRELOAD
+            if constexpr (STEADY) {
+                // All K fragments of the tile are requested before the first MFMA and the two 32-key chains are
+                // interleaved.  Left alone, hipcc keeps ONE fragment buffer to save registers and emits
+                // ds_read -> wait -> MFMA six times per tile, exposing the LDS latency every time.
+                v4i kf[NS][C::KSTEPS];
+#pragma unroll
+                for (int sb = 0; sb < NS; sb++) {
+                    const int krow = sb * 32 + n;
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+                        kf[sb][kk] = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sb = 0; sb < NS; sb++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) s[sb][i] = 0;
+#pragma unroll
+                for (int kk = 0; kk < C::KSTEPS; kk++)
+#pragma unroll
+                    for (int sb = 0; sb < NS; sb++)
+                        s[sb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
+            } else
+#endif
 #pragma unroll
             for (int sb = 0; sb < NS; sb++) {
 #pragma unroll
@@ -552,17 +580,25 @@ sage_attn_kernel(const AttnParams p)
                     // the MFMA of d-tile dt+1 is still in the matrix pipe (hipcc otherwise reuses one accumulator
                     // and serialises MFMA -> wait -> 8 packed FMAs four times per tile).
                     const v8i bv = {pw[0][0], pw[0][1], pw[0][2], pw[0][3], pw[0][4], pw[0][5], pw[0][6], pw[0][7]};
-                    auto pv_tile = [&](int dt) -> v16f {
+                    // all V fragments of the tile are requested up front (the S registers are dead by now), so the
+                    // LDS latency is paid once per tile instead of once per d-tile
+                    v4u va[C::DT], vb[C::DT];
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; dt++) {
                         const int drow = dt * 32 + n;
                         const unsigned char *vr = vs + drow * 64;
-                        const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                        const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-                        const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
+                        va[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
+                        vb[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
+                    }
+                    auto pv_tile = [&](int dt) -> v16f {
+                        const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3],
+                                        (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
                         v16f z;
 #pragma unroll
                         for (int i = 0; i < 16; i++) z[i] = 0.0f;
                         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, z, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                     };
+#if SAGE_PV2BUF == 2
                     v16f t0 = pv_tile(0);
                     v16f t1 = pv_tile(1);
 #pragma unroll
@@ -572,6 +608,14 @@ sage_attn_kernel(const AttnParams p)
                         for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, t[i]);
                         if (dt + 2 < C::DT) t = pv_tile(dt + 2);
                     }
+#else
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; dt++) {
+                        const v16f t = pv_tile(dt);
+#pragma unroll
+                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, t[i]);
+                    }
+#endif
                 } else
 #endif
 #pragma unroll
