@@ -231,12 +231,20 @@ def main():
     dist_on = world > 1
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    # dry-run aid for a 1-GPU box: SAGE_BENCH_BACKEND=gloo puts every rank on cuda:0 and uses gloo for the
+    # barrier / MAX-reduce, to exercise the multi-process control flow without RCCL (never used by the driver)
+    backend = os.environ.get("SAGE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sageattention_amd import _cabi
     _cabi.load()
@@ -295,15 +303,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         if args.sweep:
-            sweep = {}
-            for n in (1024, 2048, 4096, 8192, 16384, 32768):
-                c = dict(cfg, N=n)
-                qq, kk, vv = make_inputs(c, device, seed=n)
-                oo = prequantize(c, qq, kk, vv)
-                _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 20, 5, False, min(args.ramp_seconds, 0.2))
-                sweep[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
-                del qq, kk, vv, oo
-            out["sweep_kernel_only_tflops"] = sweep
+            # the config's batch (BASELINE.json: 2) and the reference bench scripts' default batch (4,
+            # bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7) -- 256 CUs need the larger grid at short sequences
+            for key, bsz in (("sweep_kernel_only_tflops", cfg["B"]), ("sweep_kernel_only_tflops_batch4", 4)):
+                sweep = {}
+                for n in (1024, 2048, 4096, 8192, 16384, 32768):
+                    c = dict(cfg, N=n, B=bsz)
+                    qq, kk, vv = make_inputs(c, device, 99)
+                    oo = prequantize(c, qq, kk, vv)
+                    _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 20, 5, False, min(args.ramp_seconds, 0.2))
+                    sweep[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
+                    del qq, kk, vv, oo
+                out[key] = sweep
         print(json.dumps(out))
     if dist_on:
         dist.barrier()
