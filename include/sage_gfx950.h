@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 4
+#define SAGE_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -214,6 +214,18 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                                     int64_t o_sl, int64_t o_sh,
                                     int is_causal, float sm_scale_log2, int pv_accum, int out_dtype,
                                     void *stream);
+
+/* Merge a partial attention state into a running FP32 state by log-sum-exp (natural log), in place:
+ *   m = max(lse_acc, lse_new); w_a = e^(lse_acc-m); w_b = e^(lse_new-m);
+ *   o_acc = (o_acc w_a + o_new w_b) / (w_a + w_b);  lse_acc = m + log(w_a + w_b)
+ * first != 0 initialises the state from (o_new, lse_new).  o_out (nullable) additionally receives the merged
+ * output in the dtype of o_new (pass it on the last step).  o_acc [B,H,L,D] fp32 and lse_* [B,H,L] fp32 are
+ * contiguous; o_new / o_out take element strides (HND or NHD views).
+ * Replaces: the LSE combine a sequence-parallel caller performs on `sageattn(..., return_lse=True)` results
+ * (core.py:782-786,823-826; example/parallel_sageattn_cogvideo.py drives it through xfuser's ring attention). */
+SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,
+                               int B, int H, int L, int D, int64_t n_sb, int64_t n_sh, int64_t n_sl,
+                               int64_t o_sb, int64_t o_sh, int64_t o_sl, int dtype, int first, void *stream);
 
 #ifdef __cplusplus
 }

@@ -296,4 +296,25 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                        is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order);
 }
 
+SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,
+                               int B, int H, int L, int D, int64_t n_sb, int64_t n_sh, int64_t n_sl,
+                               int64_t o_sb, int64_t o_sh, int64_t o_sl, int dtype, int first, void *stream)
+{
+    SAGE_REQUIRE(o_acc && lse_acc && o_new && lse_new, "null tensor pointer");
+    SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem (B=%d H=%d L=%d)", B, H, L);
+    SAGE_REQUIRE(D > 0 && D % 8 == 0, "head_dim must be a positive multiple of 8 (got %d)", D);
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(aligned16(o_acc) && aligned16(o_new) && (o_out == nullptr || aligned16(o_out)), "o tensors must be 16-byte aligned");
+    SAGE_REQUIRE(n_sb % 8 == 0 && n_sh % 8 == 0 && n_sl % 8 == 0, "o_new strides must be multiples of 8 elements");
+    SAGE_REQUIRE(o_out == nullptr || (o_sb % 8 == 0 && o_sh % 8 == 0 && o_sl % 8 == 0), "o_out strides must be multiples of 8 elements");
+    sage::MergeParams p{};
+    p.o_acc = o_acc; p.lse_acc = lse_acc; p.o_new = o_new; p.lse_new = lse_new; p.o_out = o_out;
+    p.B = B; p.H = H; p.L = L; p.D = D;
+    p.n_sb = n_sb; p.n_sh = n_sh; p.n_sl = n_sl; p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl;
+    p.dtype = dtype; p.first = first != 0;
+    const hipError_t e = sage::launch_merge_states(p, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(SAGE_ELAUNCH, "sage_merge_states launch: %s", hipGetErrorString(e));
+    return SAGE_OK;
+}
+
 }  // extern "C"

@@ -97,4 +97,19 @@ struct PrepVParams {
 };
 hipError_t launch_prep_v(const PrepVParams &p, hipStream_t stream);
 
+// ---- LSE merge of partial attention states (sequence-parallel callers) -----------------------------
+struct MergeParams {
+    float *o_acc;             // [B,H,L,D] fp32 running output, contiguous
+    float *lse_acc;           // [B,H,L] fp32 running log-sum-exp (natural log), contiguous
+    const void *o_new;        // fp16 / bf16 partial output, element strides below
+    const float *lse_new;     // [B,H,L] contiguous
+    void *o_out;              // nullable: also write the merged output in the dtype of o_new (last step)
+    int B, H, L, D;
+    long n_sb, n_sh, n_sl;    // o_new strides
+    long o_sb, o_sh, o_sl;    // o_out strides
+    int dtype;
+    int first;                // 1: initialise the running state from (o_new, lse_new)
+};
+hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream);
+
 }  // namespace sage

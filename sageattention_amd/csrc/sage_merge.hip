@@ -1,0 +1,83 @@
+// sage_merge.hip -- merge of two partial attention states by their log-sum-exp (HBM-bound, elementwise).
+//
+// The reference exposes `return_lse` (core.py:782-786, 823-826) as its only long-context hook: sequence-parallel
+// callers (ring attention, example/parallel_sageattn_cogvideo.py via xfuser) run attention against one K/V shard at
+// a time and combine the partial outputs with
+//     m = max(lse_a, lse_b);  w_a = e^(lse_a - m);  w_b = e^(lse_b - m)
+//     o = (o_a w_a + o_b w_b) / (w_a + w_b);        lse = m + log(w_a + w_b)
+// This kernel keeps the running state (o_acc, lse_acc) in FP32 across the steps of the ring so the output is
+// rounded to fp16/bf16 exactly once, at the last step.  One thread owns 8 channels of one (batch, head, row):
+// 32 B of accumulator + 16 B of new output in, 32 B (+16 B on the last step) out.
+#include "sage_common.h"
+#include "sage_kernels.h"
+
+namespace sage {
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+merge_states_kernel(const MergeParams p)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = p.D / 8;                        // 8-channel chunks per row
+    const long row = t / cpr;
+    if (row >= (long)p.B * p.H * p.L) return;
+    const int c8 = (int)(t - row * cpr) * 8;
+    const int l = (int)(row % p.L);
+    const long bh = row / p.L;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+
+    const uint16_t *on = reinterpret_cast<const uint16_t *>(p.o_new) + (long)b * p.n_sb + (long)h * p.n_sh + (long)l * p.n_sl + c8;
+    float *acc = p.o_acc + row * p.D + c8;
+    const v4u raw = *reinterpret_cast<const v4u *>(on);
+    float xn[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned w = raw[j >> 1];
+        xn[j] = ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+    }
+    const float ln = p.lse_new[row];
+    float r[8], lse;
+    if (p.first) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = xn[j];
+        lse = ln;
+    } else {
+        const float la = p.lse_acc[row];
+        const float m = fmaxf(la, ln);
+        if (m == -INFINITY) {                       // neither side attended to anything: keep the (zero) state
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = 0.0f;
+            lse = -INFINITY;
+        } else {
+            const float wa = __expf(la - m), wb = __expf(ln - m);
+            const float s = wa + wb, inv = 1.0f / s;
+            const v4f a0 = *reinterpret_cast<const v4f *>(acc), a1 = *reinterpret_cast<const v4f *>(acc + 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = ((j < 4 ? a0[j] : a1[j - 4]) * wa + xn[j] * wb) * inv;
+            lse = m + __logf(s);
+        }
+    }
+    v4f o0 = {r[0], r[1], r[2], r[3]}, o1 = {r[4], r[5], r[6], r[7]};
+    *reinterpret_cast<v4f *>(acc) = o0;
+    *reinterpret_cast<v4f *>(acc + 4) = o1;
+    if (c8 == 0) p.lse_acc[row] = lse;
+    if (p.o_out != nullptr) {
+        uint16_t *oo = reinterpret_cast<uint16_t *>(p.o_out) + (long)b * p.o_sb + (long)h * p.o_sh + (long)l * p.o_sl + c8;
+        v4u pk;
+#pragma unroll
+        for (int w = 0; w < 4; w++) pk[w] = (unsigned)st16<DT>(r[2 * w]) | ((unsigned)st16<DT>(r[2 * w + 1]) << 16);
+        *reinterpret_cast<v4u *>(oo) = pk;
+    }
+}
+
+hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream)
+{
+    const long threads = (long)p.B * p.H * p.L * (p.D / 8);
+    if (threads <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (p.dtype == DT_F16) hipLaunchKernelGGL(merge_states_kernel<DT_F16>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(merge_states_kernel<DT_BF16>, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace sage

@@ -548,3 +548,63 @@ def test_config4_varlen_gqa():
             cos = util.cos_sim(got, truth.cpu().numpy())
             REPORT[f"full/c4_varlen/{'c' if causal else 'nc'}/seq{i}"] = dict(cos=cos)
             assert cos >= 0.9995
+
+
+# ------------------------------------------------------------------------------------------------ LSE merge / ring caller
+@pytest.mark.parametrize("dt,layout,D,L", [(0, "HND", 128, 333), (1, "NHD", 64, 130), (1, "HND", 96, 17)])
+def test_merge_states_matches_formula(dt, layout, D, L):
+    """sage_merge_states (sequence-parallel combine of return_lse results) vs the fp32 formula, incl. -inf rows."""
+    from sageattention_amd import ring
+    g = torch.Generator().manual_seed(12)
+    B, H = 2, 3
+    oa, ob = torch.randn(B, H, L, D, generator=g).to(T(dt)), torch.randn(B, H, L, D, generator=g).to(T(dt))
+    la, lb = 4.0 * torch.randn(B, H, L, generator=g), 4.0 * torch.randn(B, H, L, generator=g)
+    lb[0, 0, :5] = float("-inf")                      # shard contributed nothing to these rows
+    la[1, 2, 3] = float("-inf")
+    la[1, 1, 7] = lb[1, 1, 7] = float("-inf")          # nobody did
+    acc_ref, lse_ref = torch.empty(B, H, L, D), torch.empty(B, H, L)
+    util.merge_states_torch(acc_ref, lse_ref, oa if layout == "HND" else oa.transpose(1, 2), la, layout, first=True)
+    out_ref = torch.empty_like(oa if layout == "HND" else oa.transpose(1, 2).contiguous())
+    util.merge_states_torch(acc_ref, lse_ref, ob if layout == "HND" else ob.transpose(1, 2), lb, layout, out=out_ref)
+
+    acc = torch.empty(B, H, L, D, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
+    oad, obd = to_dev(oa, layout), to_dev(ob, layout)
+    out = torch.empty_like(oad)
+    ring.merge_states(acc, lse, oad, la.to(DEV), layout, first=True)
+    assert torch.equal(acc.cpu(), oa.float()) and torch.equal(lse.cpu(), la)
+    ring.merge_states(acc, lse, obd, lb.to(DEV), layout, out=out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(acc).all()
+    assert (acc.cpu() - acc_ref).abs().max().item() <= 1e-5 * acc_ref.abs().max().item()
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isfinite(lse.cpu()), fin) and (lse.cpu()[fin] - lse_ref[fin]).abs().max().item() <= 1e-5
+    ulp = 2.0 ** (-10 if dt == 0 else -7)
+    assert ((out.float().cpu() - out_ref.float()).abs() <= ulp * out_ref.float().abs().clamp_min(2.0 ** -14)).all()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_ring_steps_on_one_gpu_match_full_attention(causal):
+    """The ring caller's per-rank computation replayed on one device: rank r of 3 attends shard by shard with
+    sageattn(return_lse=True) and merges with the HIP kernel; the result must meet the FP8 accuracy bound against
+    fp32 SDPA over the whole sequence (shard-wise K smoothing / scales differ from the unsharded call, so the
+    comparison is against the truth, not bit-for-bit against a single call)."""
+    from sageattention_amd import ring
+    W, B, H, Lc, D = 3, 1, 4, 384, 128
+    q, k, v = rand_qkv(B, H, H, W * Lc, W * Lc, D, 1, seed=21, kbias=1.0)
+    truth = util.sdpa_f32(q, k, v, causal).numpy()
+    for r in range(W):
+        qs = q[:, :, r * Lc:(r + 1) * Lc].to(DEV)
+        acc = torch.empty(B, H, Lc, D, dtype=torch.float32, device=DEV)
+        lse = torch.empty(B, H, Lc, dtype=torch.float32, device=DEV)
+        out = torch.empty_like(qs)
+        sched = [(s, j, m) for s, j, m in ring.shard_schedule(r, W, causal) if m != "skip"]
+        for idx, (s, j, mode) in enumerate(sched):
+            ks, vs = k[:, :, j * Lc:(j + 1) * Lc].to(DEV), v[:, :, j * Lc:(j + 1) * Lc].to(DEV)
+            o_s, lse_s = sa.sageattn(qs, ks, vs, is_causal=(mode == "causal"), return_lse=True)
+            ring.merge_states(acc, lse, o_s, lse_s, first=(idx == 0), out=out if idx == len(sched) - 1 else None)
+        got = out.float().cpu().numpy()
+        want = truth[:, :, r * Lc:(r + 1) * Lc]
+        rel = util.rmse(got, want) / float(np.sqrt((want ** 2).mean()))
+        REPORT[f"ring/{'c' if causal else 'nc'}/rank{r}"] = dict(rel_rmse=rel, cos=util.cos_sim(got, want))
+        assert util.cos_sim(got, want) >= 0.999 and rel <= 0.05

@@ -101,3 +101,46 @@ def sdpa_f32(q, k, v, causal, sm_scale=None):
         m = torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).tril()
         s = s.masked_fill(~m, float("-inf"))
     return torch.matmul(torch.softmax(s, dim=-1), vf)
+
+
+# ---- LSE merge reference (sequence-parallel callers; sageattention_amd/ring.py) -------------------------------------
+def attn_with_lse_f32(q, k, v, tensor_layout="HND", is_causal=False, sm_scale=None, return_lse=True, **_):
+    """Plain fp32 attention with the natural-log LSE, top-left causal mask (what sageattn(return_lse=True) returns)."""
+    import torch
+    if tensor_layout == "NHD":
+        q, k, v = (x.transpose(1, 2) for x in (q, k, v))
+    qf, kf, vf = q.float(), k.float(), v.float()
+    g = qf.shape[1] // kf.shape[1]
+    if g > 1:
+        kf, vf = kf.repeat_interleave(g, 1), vf.repeat_interleave(g, 1)
+    s = (qf @ kf.transpose(-1, -2)) * (sm_scale if sm_scale is not None else q.shape[-1] ** -0.5)
+    if is_causal:
+        Lq, Lk = s.shape[-2:]
+        s = s.masked_fill(torch.ones(Lq, Lk, dtype=torch.bool).triu(1), float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    o = (torch.softmax(s, dim=-1) @ vf).to(q.dtype)
+    if tensor_layout == "NHD":
+        o = o.transpose(1, 2)
+    return o, lse
+
+
+def merge_states_torch(o_acc, lse_acc, o_new, lse_new, tensor_layout="HND", first=False, out=None):
+    """The formula of sage_merge_states in torch (fp32), in place on (o_acc [B,H,L,D], lse_acc [B,H,L])."""
+    import torch
+    on = o_new.float()
+    if tensor_layout == "NHD":
+        on = on.transpose(1, 2)
+    if first:
+        o_acc.copy_(on)
+        lse_acc.copy_(lse_new)
+    else:
+        m = torch.maximum(lse_acc, lse_new)
+        wa = torch.exp(lse_acc - m).unsqueeze(-1)
+        wb = torch.exp(lse_new - m).unsqueeze(-1)
+        dead = (m == float("-inf")).unsqueeze(-1)
+        res = torch.where(dead, torch.zeros_like(on), (o_acc * wa + on * wb) / (wa + wb))
+        lse = torch.where(dead.squeeze(-1), m, m + torch.log((wa + wb).squeeze(-1)))
+        o_acc.copy_(res)
+        lse_acc.copy_(lse)
+    if out is not None:
+        out.copy_((o_acc.transpose(1, 2) if tensor_layout == "NHD" else o_acc).to(out.dtype))
