@@ -608,3 +608,62 @@ def test_ring_steps_on_one_gpu_match_full_attention(causal):
         rel = util.rmse(got, want) / float(np.sqrt((want ** 2).mean()))
         REPORT[f"ring/{'c' if causal else 'nc'}/rank{r}"] = dict(rel_rmse=rel, cos=util.cos_sim(got, want))
         assert util.cos_sim(got, want) >= 0.999 and rel <= 0.05
+
+
+# ------------------------------------------------------------------------------------------------ randomized sweep + graphs
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_shapes_vs_oracle(oracle_mod, seed):
+    """Seeded random problems (shapes around the 64/128 tile edges and the steady/general loop boundary, GQA, both head
+    dims, every granularity and accumulation mode, both layouts) against the oracle on identical operands."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([64, 128]))
+    Hkv = int(rng.integers(1, 4))
+    Hq = Hkv * int(rng.choice([1, 2, 4]))
+    B = int(rng.integers(1, 3))
+    Lk = int(rng.choice([int(rng.integers(1, 200)), int(rng.integers(190, 330)), int(rng.integers(500, 900))]))
+    causal = bool(rng.integers(0, 2))
+    Lq = Lk if (causal and rng.random() < 0.7) else int(rng.integers(1, 420))
+    dt = int(rng.integers(0, 2))
+    gran = str(rng.choice(["per_block", "per_warp", "per_thread"]))
+    pv = str(rng.choice(["f8_two", "f8_single", "f16_two", "f16_single"]))
+    layout = str(rng.choice(["HND", "NHD"]))
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
+    fp8 = pv.startswith("f8")
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal,
+                                                   pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km,
+                                                   warpq=16 if (pv == "f16_two" and D == 128) else 32)
+    fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
+    accum = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}[pv]
+    o, lse = fn(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout, is_causal=causal,
+                qk_quant_gran=gran, pv_accum_dtype=accum, return_lse=True)
+    torch.cuda.synchronize()
+    got, ref = to_hnd(o, layout).float().cpu().numpy(), util.f32(o_bits, dt)
+    desc = f"B{B} Hq{Hq} Hkv{Hkv} Lq{Lq} Lk{Lk} D{D} dt{dt} causal{causal} {gran} {pv} {layout}"
+    assert np.isfinite(got).all(), desc
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    assert err <= 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale, f"{desc}: {err:.3e} vs {scale:.3e}"
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3, desc
+
+
+def test_sageattn_is_hip_graph_capturable():
+    """The dense pipeline (K mean, quantisers, V pre-pass, attention) has no host synchronisation and launches on the
+    caller's stream, so a serving loop can capture it in a HIP graph and replay it with new inputs in place."""
+    q, k, v = (t.to(DEV) for t in rand_qkv(1, 8, 8, 1024, 1024, 128, 1, seed=5))
+    sa.sageattn(q, k, v, is_causal=True)                       # warm-up outside capture (library load, allocator)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        sa.sageattn(q, k, v, is_causal=True)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        o_graph = sa.sageattn(q, k, v, is_causal=True)
+    q2, k2, v2 = (t.to(DEV) for t in rand_qkv(1, 8, 8, 1024, 1024, 128, 1, seed=6))
+    q.copy_(q2); k.copy_(k2); v.copy_(v2)
+    g.replay()
+    torch.cuda.synchronize()
+    want = sa.sageattn(q2, k2, v2, is_causal=True)
+    assert torch.equal(o_graph, want)
