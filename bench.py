@@ -49,6 +49,9 @@ CONFIGS = {
     "h12": dict(B=1, H=12, Hkv=12, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=12 N=8192 causal"),
     "d64f16": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp16", dtype="fp16", workload="probe D=64 FP16 PV B=2 H=32 N=8192 causal"),
     "d64f8": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp8", dtype="bf16", workload="probe D=64 FP8 PV B=2 H=32 N=8192 causal"),
+    "n1k": dict(B=2, H=32, Hkv=32, N=1024, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=1024"),
+    "n2k": dict(B=2, H=32, Hkv=32, N=2048, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=2048"),
+    "n4k": dict(B=2, H=32, Hkv=32, N=4096, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=4096"),
     "h4": dict(B=1, H=4, Hkv=4, N=16384, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=4 N=16384 causal"),
 }
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, fp8 5.0 PF (the MX-scaled
