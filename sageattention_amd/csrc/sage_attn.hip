@@ -37,9 +37,6 @@
 #ifndef SAGE_MXPV       // FP8 PV on the block-scaled K=64 MFMA with unit scales (+5%)
 #define SAGE_MXPV 1
 #endif
-#ifndef SAGE_PV2BUF     // two PV tile accumulators in flight (fold of d-tile dt overlaps the MFMA of dt+1)
-#define SAGE_PV2BUF 0
-#endif
 #ifndef SAGE_KPRELOAD   // steady iteration: request all K fragments before the first QK MFMA
 #define SAGE_KPRELOAD 1
 #endif
@@ -111,47 +108,16 @@ sage_attn_kernel(const AttnParams p)
         h = hk * p.group + hg;
     } else {
         // workgroups bid, bid+8, bid+16.. share an XCD (bid % 8); each XCD takes one contiguous run of work items,
-        // so the q-blocks of one head -- and the query heads of one GQA group -- stream K/V through one L2.
-        // SAGE_XCD_MAP=1 (experiment): whole heads dealt in rounds of 8, left-over heads q-block by q-block.  Better
-        // balanced for causal head counts that are not multiples of 8, but it spreads a GQA group / a long head's
-        // K/V over all eight L2s and measured 6-14 % slower there (profiles/r1_run28_xcd_map.txt).
+        // so the q-blocks of one head -- and the query heads of one GQA group -- stream K/V through one L2, and the
+        // longest (causal) blocks of a head are dispatched first.  Measured alternatives (profiles/r1_run28_xcd_map.txt,
+        // DESIGN.md 3.1): heads dealt to XCDs in rounds of 8 is 6-14 % slower where it spreads a head's K/V over all
+        // eight L2s; shortest-first order -5 %, alternating long/short -21 %.
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-        const int nbh = p.B * p.Hq;
-#ifndef SAGE_XCD_MAP
-#define SAGE_XCD_MAP 0
-#endif
-#if SAGE_XCD_MAP == 1
-        const int full = (nbh >> 3) * nqblk;          // work items per XCD from whole rounds
-        int bh, r_;
-        if (idx < full) {
-            const int rd = idx / nqblk;
-            bh = rd * 8 + xcd;
-            r_ = idx - rd * nqblk;
-        } else {
-            const int gidx = (idx - full) * 8 + xcd;  // interleaved over the left-over heads
-            const int hh = gidx / nqblk;
-            bh = (nbh & ~7) + hh;
-            if (bh >= nbh) return;
-            r_ = gidx - hh * nqblk;
-        }
-#else
         const int nwg = gridDim.x;
         const int qq = nwg >> 3, rr = nwg & 7;
         const int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
         const int bh = wid / nqblk;
-        const int r_ = wid - bh * nqblk;
-        if (bh >= nbh) return;
-#endif
-#ifndef SAGE_ORDER
-#define SAGE_ORDER 0
-#endif
-#if SAGE_ORDER == 0
-        qblk = nqblk - 1 - r_;                   // longest (causal) blocks first
-#elif SAGE_ORDER == 1
-        qblk = r_;                               // experiment: shortest first
-#else
-        qblk = (r_ & 1) ? (r_ >> 1) : (nqblk - 1 - (r_ >> 1));   // experiment: alternate long / short
-#endif
+        qblk = nqblk - 1 - (wid - bh * nqblk);
         b = bh / p.Hq;
         h = bh - b * p.Hq;
         hk = h / p.group;
@@ -362,9 +328,7 @@ sage_attn_kernel(const AttnParams p)
         if constexpr (NSTAGE == 3) {
             if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef SAGE_EXP_NOBAR          // timing probe only (results are wrong without the barrier)
             __builtin_amdgcn_s_barrier();
-#endif
         } else {
             __syncthreads();
         }
@@ -574,50 +538,6 @@ sage_attn_kernel(const AttnParams p)
                 if (full) build_p(std::false_type{});
                 else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;      // lane-partial; the pair is summed in the epilogue
-#if SAGE_PV2BUF && SAGE_MXPV
-                if constexpr (TWO_LEVEL && NH == 1) {
-                    // Two tile accumulators in flight: the O = O*alpha + T fold of d-tile dt runs on the VALU while
-                    // the MFMA of d-tile dt+1 is still in the matrix pipe (hipcc otherwise reuses one accumulator
-                    // and serialises MFMA -> wait -> 8 packed FMAs four times per tile).
-                    const v8i bv = {pw[0][0], pw[0][1], pw[0][2], pw[0][3], pw[0][4], pw[0][5], pw[0][6], pw[0][7]};
-                    // all V fragments of the tile are requested up front (the S registers are dead by now), so the
-                    // LDS latency is paid once per tile instead of once per d-tile
-                    v4u va[C::DT], vb[C::DT];
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vs + drow * 64;
-                        va[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                        vb[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-                    }
-                    auto pv_tile = [&](int dt) -> v16f {
-                        const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3],
-                                        (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
-                        v16f z;
-#pragma unroll
-                        for (int i = 0; i < 16; i++) z[i] = 0.0f;
-                        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, z, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                    };
-#if SAGE_PV2BUF == 2
-                    v16f t0 = pv_tile(0);
-                    v16f t1 = pv_tile(1);
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        v16f &t = (dt & 1) ? t1 : t0;
-#pragma unroll
-                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, t[i]);
-                        if (dt + 2 < C::DT) t = pv_tile(dt + 2);
-                    }
-#else
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        const v16f t = pv_tile(dt);
-#pragma unroll
-                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, t[i]);
-                    }
-#endif
-                } else
-#endif
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) {
                     const int drow = dt * 32 + n;
@@ -830,13 +750,7 @@ hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool caus
                        bool two_level, int mask_kind, hipStream_t stream)
 {
     // varlen grids are padded to whole rounds of 8 (sequence, kv-head) units, see the work-item mapping
-    const int nbh = p.B * p.Hq;
-#if defined(SAGE_XCD_MAP) && SAGE_XCD_MAP == 1
-    const int dense_work = (nbh / 8) * 8 * p.nqblk + (((nbh % 8) * p.nqblk + 7) / 8) * 8;
-#else
-    const int dense_work = nbh * p.nqblk;
-#endif
-    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : dense_work;
+    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
         if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)
