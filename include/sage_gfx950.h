@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 5
+#define SAGE_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -214,6 +214,20 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                                     int64_t o_sl, int64_t o_sh,
                                     int is_causal, float sm_scale_log2, int pv_accum, int out_dtype,
                                     void *stream);
+
+/* FP8-PV attention (two-level accumulation, "per-thread" granularity) with the Q quantisation fused into the kernel:
+ * q is the fp16 / bf16 query tensor itself (element strides); each workgroup quantises its 128 rows in registers with
+ * exactly the arithmetic of sage_quant_qk_int8(gran = per_thread, style = SAGE_QSTYLE_TRITON_THREAD, pre_scale = 1), so
+ * the result is bit-identical to sage_quant_qk_int8 + sage_attn_qk_int8_pv_f8 while the INT8 copy of Q and its scales
+ * never touch HBM (3 B/element of pre-pass traffic and one launch less).  k / k_scale are the per-thread-quantised keys.
+ * Replaces: quant_per_thread.py:154-188 (the q half) + qk_int_sv_f8_cuda_sm90.cu / sm89 fuse_v_scale ops called in
+ * sequence by core.py:773-821. */
+SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                     const float *k_scale, const float *v_scale, const float *v_mean,
+                                     int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                     int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                     int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
 
 /* Merge a partial attention state into a running FP32 state by log-sum-exp (natural log), in place:
  *   m = max(lse_acc, lse_new); w_a = e^(lse_acc-m); w_b = e^(lse_new-m);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
@@ -44,6 +44,8 @@ SYMBOLS = {
                                                 _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P]),
     "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+    "sage_attn_fused_q_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_merge_states": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _P]),
 }
 

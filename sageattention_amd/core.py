@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _cabi, ops
-from .quant import (LOG2E, _dims, _p, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
+from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
                     per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, sub_mean)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
@@ -90,6 +90,26 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
         lse = f16(q_int8, k_int8, v_image, o, q_scale, k_scale, v_mean, layout, int(is_causal),
                   gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
     return o, (lse if return_lse else None)
+
+
+@torch.compiler.disable
+def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None):
+    """FP8-PV two-level attention with the per-thread Q quantisation done in the kernel prologue
+    (``sage_attn_fused_q_pv_f8``): bit-identical to ``per_thread_int8`` + the attention op, one launch and
+    3 B/element of HBM traffic less."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
+    assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
+    o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
+    code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_fused_q_pv_f8(
+        _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_scale), _p(v_mean),
+        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+        int(is_causal), float(sm_scale_log2), code, code, _stream(q))
+    _cabi.check(rc, "sage_attn_fused_q_pv_f8")
+    return o, lse
 
 
 @torch.compiler.disable
@@ -276,6 +296,16 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     if pv_accum_dtype in ("fp32+fp32", "fp32+fp16") and smooth_v:
         warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")   # core.py:797-803
         smooth_v = False
+    fuse_q = (qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
+              and not torch.compiler.is_compiling())
+    if fuse_q:
+        # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM)
+        km_s = _squeeze_km(km, tensor_layout)
+        k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
+        v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+        o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale * LOG2E,
+                               return_lse, v_mean=vm)
+        return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)
     v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,

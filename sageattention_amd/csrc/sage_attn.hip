@@ -27,6 +27,7 @@
 //  * output tile is transposed through (now free) LDS and stored as whole rows, 16 B per lane.
 #include "sage_common.h"
 #include "sage_kernels.h"
+#include "sage_quant_math.h"
 #include <climits>
 #include <type_traits>
 
@@ -73,7 +74,9 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 // c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0>
+// QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue
+// ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
+template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
 sage_attn_kernel(const AttnParams p)
 {
@@ -167,18 +170,16 @@ sage_attn_kernel(const AttnParams p)
 
     // ---- Q fragments (B operand of S^T = K Q^T), resident in VGPRs ---------------------------
     v4i qf[C::KSTEPS];
-    {
-        const int8_t *qrow = p.q + q_off + (long)my_row * p.q_sl;
+    float qsc;
+    if constexpr (QF == 0) {
+        const int8_t *qrow = reinterpret_cast<const int8_t *>(p.q) + q_off + (long)my_row * p.q_sl;
         const bool ok = my_row < Lq;
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             v4i z = {0, 0, 0, 0};
             qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
         }
-    }
-    // this lane's query-row scale (per-block / per-warp / per-thread granularity)
-    float qsc;
-    {
+        // this lane's query-row scale (per-block / per-warp / per-thread granularity)
         int slot;
         const int rin = wave * 32 + n;               // row inside the 128-row block
         if (p.q_gran == QG_PER_BLOCK) slot = 0;
@@ -186,6 +187,46 @@ sage_attn_kernel(const AttnParams p)
         else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
         else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
         qsc = qs_ptr[slot * qs_stride] * p.sm_scale_log2;
+    } else {
+        // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
+        // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
+        // r, r+8, r+16, r+24 of the wave's 32-row tile, all 128 channels: lanes n = r (mod 8), both halves g.
+        constexpr int QDT = (QF == 1) ? DT_F16 : DT_BF16;
+        const uint16_t *qrow = reinterpret_cast<const uint16_t *>(p.q) + q_off + (long)my_row * p.q_sl;
+        const bool ok = my_row < Lq;
+        float x[C::KSTEPS][16];
+        float amax = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ks++) {
+            v4u raw[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (ok) {
+                raw[0] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g);
+                raw[1] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const unsigned w = raw[j >> 3][(j & 7) >> 1];
+                const float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                x[ks][j] = f;
+                amax = fmaxf(amax, fabsf(f));
+            }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 8));
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        const float sc = quant_scale(amax, QS_TRITON_THREAD);
+        const float y = quant_recip(sc);
+        qsc = sc * p.sm_scale_log2;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ks++) {
+            int q8[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton(x[ks][j], sc, y);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                qf[ks][w] = (int)((unsigned)(q8[4 * w] & 0xff) | ((unsigned)(q8[4 * w + 1] & 0xff) << 8) |
+                                  ((unsigned)(q8[4 * w + 2] & 0xff) << 16) | ((unsigned)(q8[4 * w + 3] & 0xff) << 24));
+        }
     }
 
     // ---- tile staging ------------------------------------------------------------------------
@@ -744,6 +785,29 @@ static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stre
     auto kern = sage_attn_kernel<D, false, false, false, true, 1, MASK>;
     hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
     return hipGetLastError();
+}
+
+template <int D, bool CAUSAL, int QF>
+static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t stream)
+{
+    using C = TileCfg<D, true, SAGE_NH_F8>;
+    auto kern = sage_attn_kernel<D, true, CAUSAL, true, true, SAGE_NH_F8, 0, QF>;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+// FP8 PV, two-level accumulation, per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel
+hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream)
+{
+    const int nwork = p.B * p.Hq * p.nqblk;
+    if (nwork <= 0) return hipSuccess;
+    if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
+#define SAGE_FQ(D_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, false, 1>(p, nwork, stream); \
+                         return causal ? launch_fused_q_one<D_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, false, 2>(p, nwork, stream); } while (0)
+    if (head_dim == 128) SAGE_FQ(128);
+    if (head_dim == 64) SAGE_FQ(64);
+#undef SAGE_FQ
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,

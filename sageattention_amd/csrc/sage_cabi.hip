@@ -296,6 +296,41 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                        is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order);
 }
 
+SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                     const float *k_scale, const float *v_scale, const float *v_mean,
+                                     int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                     int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                     int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(q && k && v_image && o && k_scale && v_scale, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
+    SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0 && Lk > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d Lk=%d)", B, Hq, Hkv, Lq, Lk);
+    SAGE_REQUIRE(Hq % Hkv == 0, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+    SAGE_REQUIRE(q_dtype == SAGE_DTYPE_F16 || q_dtype == SAGE_DTYPE_BF16, "bad q_dtype %d", q_dtype);
+    SAGE_REQUIRE(out_dtype == SAGE_DTYPE_F16 || out_dtype == SAGE_DTYPE_BF16, "bad out_dtype %d", out_dtype);
+    SAGE_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v_image) && aligned16(o), "q/k/v/o must be 16-byte aligned");
+    SAGE_REQUIRE(q_sl % 8 == 0 && q_sh % 8 == 0 && q_sb % 8 == 0, "q strides must be multiples of 8 elements");
+    SAGE_REQUIRE(k_sl % 16 == 0 && k_sh % 16 == 0 && k_sb % 16 == 0, "int8 k strides must be multiples of 16");
+    SAGE_REQUIRE(o_sl % 8 == 0 && o_sh % 8 == 0 && o_sb % 8 == 0, "output strides must be multiples of 8 elements");
+    sage::AttnParams p{};
+    p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
+    p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+    p.Lq = Lq; p.Lk = Lk;
+    p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
+    p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+    p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl;
+    p.q_gran = sage::QG_PER_THREAD; p.qs_per_blk = 32;
+    p.nqs = p.nqblk * p.qs_per_blk;
+    p.nks = ((Lk + sage::BLKK - 1) / sage::BLKK) * 4;
+    p.out_dtype = out_dtype;
+    p.sm_scale_log2 = sm_scale_log2;
+    return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, static_cast<hipStream_t>(stream)),
+                        "sage_attn_fused_q launch");
+}
+
 SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,
                                int B, int H, int L, int D, int64_t n_sb, int64_t n_sh, int64_t n_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl, int dtype, int first, void *stream)

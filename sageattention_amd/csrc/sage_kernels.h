@@ -9,7 +9,7 @@ namespace sage {
 enum : int { QG_PER_BLOCK = 1, QG_PER_WARP32 = 2, QG_PER_THREAD = 3, QG_PER_WARP16 = 4 };
 
 struct AttnParams {
-    const int8_t *q;          // int8, strides below (elements)
+    const void *q;            // int8 (or fp16 / bf16 for the fused-Q kernels), strides below (elements)
     const int8_t *k;
     const void *v;            // gfx950 tiled V^T image (see sage_prep_v.hip)
     void *o;                  // fp16 / bf16
@@ -42,6 +42,8 @@ struct AttnParams {
 // mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
                        bool two_level, int mask_kind, hipStream_t stream);
+// q in fp16 / bf16, quantised per-thread in the kernel prologue; FP8 PV, two-level accumulation, dense only
+hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream);
 
 // ---- INT8 quantisation of Q / K ----------------------------------------------------------------
 enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style

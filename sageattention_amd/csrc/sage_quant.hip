@@ -12,6 +12,7 @@
 // with LDS atomicMax on the IEEE bit pattern (values are non-negative).
 #include "sage_common.h"
 #include "sage_kernels.h"
+#include "sage_quant_math.h"
 
 namespace sage {
 
@@ -104,11 +105,7 @@ quant_int8_kernel(const QuantParams p)
     }
     __syncthreads();
 
-    if (tid < ngroups) {
-        float sc = __uint_as_float(gmax[tid]) / 127.0f;
-        if (p.style == QS_TRITON_THREAD) sc += 1e-7f;               // quant_per_thread.py:41
-        sc_out[tid] = sc;
-    }
+    if (tid < ngroups) sc_out[tid] = quant_scale(__uint_as_float(gmax[tid]), p.style);
 
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
@@ -121,32 +118,14 @@ quant_int8_kernel(const QuantParams p)
         if (p.style == QS_CUDA) {
             const float inv = 127.0f / am;                           // fused.cu:164
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                float t = __builtin_rintf(v[i][j] * inv);            // cvt.rni.sat.s8.f32
-                t = fminf(fmaxf(t, -128.0f), 127.0f);
-                q[j] = (int)t;
-            }
+            for (int j = 0; j < 16; j++) q[j] = quant_round_cuda(v[i][j], inv);
         } else {
-            float sc = am / 127.0f;
-            if (p.style == QS_TRITON_THREAD) sc += 1e-7f;
             // x / scale must be the correctly rounded IEEE quotient (the reference divides, quant_per_block.py:41;
-            // the +-0.5 / truncate that follows makes a 1-ulp error visible in the int8).  One IEEE reciprocal per
-            // chunk, then per element the FMA-based Markstein refinement q <- q + (x - scale*q) * y, twice: the
-            // first step makes q faithful, the second makes it the correctly rounded quotient (operands are far
-            // from overflow/underflow: |x| <= 127.5 * scale).  5 full-rate VALU ops instead of the compiler's
-            // ~10-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence per element.
-            const float y = (sc == 0.0f) ? 0.0f : 1.0f / sc;
+            // the +-0.5 / truncate that follows makes a 1-ulp error visible in the int8): sage_quant_math.h
+            const float sc = quant_scale(am, p.style);
+            const float y = quant_recip(sc);
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float x = v[i][j];
-                float t = x * y;
-                t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
-                t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
-                t += (t >= 0.0f) ? 0.5f : -0.5f;
-                int qi = (int)t;                                     // truncation toward zero
-                qi = qi > 127 ? 127 : (qi < -128 ? -128 : qi);
-                q[j] = (sc == 0.0f) ? 0 : qi;
-            }
+            for (int j = 0; j < 16; j++) q[j] = quant_round_triton(v[i][j], sc, y);
         }
         v4u pk;
 #pragma unroll

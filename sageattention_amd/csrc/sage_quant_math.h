@@ -1,0 +1,43 @@
+// sage_quant_math.h -- the INT8 rounding conventions of the reference's quantisers, shared by the stand-alone
+// quantiser (sage_quant.hip) and the attention kernel's fused-Q prologue (sage_attn.hip) so both produce the same bits.
+#pragma once
+#include "sage_common.h"
+#include "sage_kernels.h"
+
+namespace sage {
+
+// scale of a quantisation group from its abs-max (QS_CUDA floors the abs-max at 1e-7 before calling, fused.cu:147)
+__device__ __forceinline__ float quant_scale(float amax, int style)
+{
+    float sc = amax / 127.0f;
+    if (style == QS_TRITON_THREAD) sc += 1e-7f;                  // quant_per_thread.py:41
+    return sc;
+}
+
+// Triton convention: x / scale (correctly rounded IEEE quotient), +-0.5, truncate, clamp (quant_per_block.py:41-44).
+// One IEEE reciprocal per group (`y`), then per element the FMA-based Markstein refinement q <- q + (x - scale*q) * y,
+// twice: the first step makes q faithful, the second makes it the correctly rounded quotient (operands are far from
+// overflow/underflow: |x| <= 127.5 * scale).  5 full-rate VALU ops instead of the compiler's ~10-instruction
+// v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence per element.
+__device__ __forceinline__ float quant_recip(float sc) { return (sc == 0.0f) ? 0.0f : 1.0f / sc; }
+
+__device__ __forceinline__ int quant_round_triton(float x, float sc, float y)
+{
+    float t = x * y;
+    t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
+    t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
+    t += (t >= 0.0f) ? 0.5f : -0.5f;
+    int qi = (int)t;                                             // truncation toward zero
+    qi = qi > 127 ? 127 : (qi < -128 ? -128 : qi);
+    return (sc == 0.0f) ? 0 : qi;
+}
+
+// CUDA convention: x * (127 / amax), round to nearest even, saturate (cvt.rni.sat.s8.f32, fused.cu:164-172)
+__device__ __forceinline__ int quant_round_cuda(float x, float inv)
+{
+    float t = __builtin_rintf(x * inv);
+    t = fminf(fmaxf(t, -128.0f), 127.0f);
+    return (int)t;
+}
+
+}  // namespace sage

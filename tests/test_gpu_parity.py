@@ -667,3 +667,26 @@ def test_sageattn_is_hip_graph_capturable():
     torch.cuda.synchronize()
     want = sa.sageattn(q2, k2, v2, is_causal=True)
     assert torch.equal(o_graph, want)
+
+
+# ------------------------------------------------------------------------------------------------ fused Q quantisation
+@pytest.mark.parametrize("shape", [(2, 4, 2, 300, 300, 128), (1, 3, 3, 129, 1000, 64), (1, 8, 8, 1024, 1024, 128), (2, 2, 1, 5, 70, 128)],
+                         ids=["gqa300", "cross_d64", "n1024", "tiny"])
+@pytest.mark.parametrize("dt,layout,causal", [(0, "HND", False), (1, "NHD", True), (1, "HND", True)])
+def test_fused_q_quant_is_bit_identical_to_the_separate_quantiser(shape, dt, layout, causal):
+    """sage_attn_fused_q_pv_f8 quantises Q in the kernel prologue with the arithmetic of the stand-alone per-thread
+    quantiser: outputs and LSE must equal the two-kernel route bit for bit (so every oracle-parity statement about
+    sageattn() carries over to the fused default route)."""
+    B, Hq, Hkv, Lq, Lk, D = shape
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=77, kbias=1.0)
+    qd, kd, vd = to_dev(q, layout), to_dev(k, layout), to_dev(v, layout)
+    o1, l1 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp32", return_lse=True)
+    o0, l0 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp32", return_lse=True,
+                                             fuse_q_quant=False)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o0) and torch.equal(l1, l0)
+    # a strided q view (fused QKV projection output) goes through the fused kernel without a copy
+    if layout == "NHD":
+        qkv = torch.stack([qd, qd, qd], dim=2)                       # [B, L, 3, H, D]
+        o2 = sa.sageattn_qk_int8_pv_fp8_cuda(qkv[:, :, 1], kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp32")
+        assert torch.equal(o2, o0)
