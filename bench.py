@@ -59,8 +59,8 @@ CONFIGS = {
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
 # HBM bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-# gfx950 correction per MI355X_MICROARCH.md); see profiles/r1_run2_pmc_c3_v1kernel.txt
-PMC_TRAFFIC_BYTES = {"c3": 336.9e6}
+# gfx950 correction per MI355X_MICROARCH.md); see profiles/r1_run48_pmc_c3_steady.txt
+PMC_TRAFFIC_BYTES = {"c3": 348.5e6}
 
 
 def blended_peak(pv: str) -> float:

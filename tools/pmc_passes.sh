@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python tools/run_kernel.py c3 3 > "$out/p$i.log" 2>&1
+  timeout 120 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python tools/run_kernel.py c3 3 > "$out/p$i.log" 2>&1
   f=$(ls "$out"/p$i/*/*counter_collection.csv 2>/dev/null | head -1)
   [ -z "$f" ] && { echo "pass $i: no counter file"; tail -3 "$out/p$i.log"; continue; }
   python3 - "$f" <<'PY'
