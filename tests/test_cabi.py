@@ -44,6 +44,20 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b"divisible" in lib.sage_last_error()
     with pytest.raises(ValueError):
         _cabi.check(rc, "x")
+    # fused-Q attention: q dtype code, kv head count, strides
+    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 128, 0, 0, 128, 0, 0, 128, 0, 1.0, 7, 0, None)
+    assert rc == -1 and b"q_dtype" in lib.sage_last_error()
+    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 132, 0, 0, 128, 0, 0, 128, 0, 1.0, 0, 0, None)
+    assert rc == -1 and b"q strides" in lib.sage_last_error()
+    # LSE merge: head_dim must be a multiple of 8, pointers non-null
+    rc = lib.sage_merge_states(p, p, p, p, None, 1, 1, 4, 12, 0, 0, 12, 0, 0, 0, 0, 0, None)
+    assert rc == -1 and b"multiple of 8" in lib.sage_last_error()
+    rc = lib.sage_merge_states(p, None, p, p, None, 1, 1, 4, 16, 0, 0, 16, 0, 0, 0, 0, 0, None)
+    assert rc == -1 and b"null" in lib.sage_last_error()
+    # varlen attention needs its prefix arrays
+    rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, None, None, None, None, None, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
+                                             0, 1.0, 1, 0, None)
+    assert rc == -1 and b"varlen" in lib.sage_last_error()
 
 
 def test_v_image_bytes():
