@@ -9,7 +9,9 @@ partial states are merged by the HIP kernel behind ``sage_merge_states`` (FP32 r
 
 Sharding: rank ``r`` of ``W`` holds the contiguous token range ``[r L/W, (r+1) L/W)`` of q, k and v.
 Causal masking at shard granularity: a shard from an earlier rank is attended in full, the rank's own shard
-causally, shards from later ranks are skipped.
+causally, shards from later ranks are skipped -- so rank 0 does one step of work and rank W-1 does W.
+``shard_order="zigzag"`` balances that: the sequence is cut into 2W chunks and rank ``r`` holds chunks ``r`` and
+``2W-1-r`` (:func:`zigzag_shard`); every rank then does the same 2c^2 of causal work per step.
 """
 from __future__ import annotations
 
@@ -59,22 +61,99 @@ def shard_schedule(rank: int, world: int, is_causal: bool):
     return sched
 
 
+def zigzag_shard(x: torch.Tensor, rank: int, world: int, tensor_layout: str = "HND") -> torch.Tensor:
+    """The zig-zag shard of a full-sequence tensor: chunks ``rank`` and ``2 world - 1 - rank`` of ``2 world``."""
+    dim = 2 if tensor_layout == "HND" else 1
+    L = x.shape[dim]
+    assert L % (2 * world) == 0, "zig-zag sharding needs the sequence length to be a multiple of 2 * world"
+    c = L // (2 * world)
+    lo, hi = x.narrow(dim, rank * c, c), x.narrow(dim, (2 * world - 1 - rank) * c, c)
+    return torch.cat([lo, hi], dim=dim)
+
+
+def zigzag_schedule(rank: int, world: int):
+    """Causal work of one rank under zig-zag sharding: [(step, kv_rank, [(q_part, kv_part, mode), ...])] with parts
+    "lo" / "hi" / "all" (the rank's first / second chunk / both) -- two or three kernel calls at step 0, one per step
+    afterwards, 2 c^2 score elements per step on every rank."""
+    sched = []
+    for s in range(world):
+        j = (rank - s) % world
+        if j == rank:
+            calls = [("lo", "lo", "causal"), ("hi", "lo", "full"), ("hi", "hi", "causal")]
+        elif j < rank:
+            calls = [("all", "lo", "full")]          # both of our chunks come after chunk j, before chunk 2W-1-j
+        else:
+            calls = [("hi", "all", "full")]          # only our late chunk sees rank j's chunks, and sees both in full
+        sched.append((s, j, calls))
+    return sched
+
+
+def _ring_zigzag_causal(q, k, v, group, tensor_layout, sm_scale, return_lse, attn_fn, merge_fn, world, rank, kwargs):
+    import torch.distributed as dist
+    dim = 2 if tensor_layout == "HND" else 1
+    B, H, L2, D, _, _, _ = _dims(q, tensor_layout)
+    assert L2 % 2 == 0
+    c = L2 // 2
+    part = lambda t, name: t if name == "all" else t.narrow(dim, 0 if name == "lo" else c, c)
+    acc = {n: torch.empty((B, H, c, D), dtype=torch.float32, device=q.device) for n in ("lo", "hi")}
+    lse = {n: torch.empty((B, H, c), dtype=torch.float32, device=q.device) for n in ("lo", "hi")}
+    out = torch.empty_like(q)
+    sched = zigzag_schedule(rank, world)
+    # per q half: the ordered list of (step, call index) that touch it, to know the first and the last merge
+    touches = {"lo": [], "hi": []}
+    for s, _, calls in sched:
+        for ci, (qp, _, _) in enumerate(calls):
+            for n in (("lo", "hi") if qp == "all" else (qp,)):
+                touches[n].append((s, ci))
+    k_cur, v_cur = k.contiguous(), v.contiguous()
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    if group is not None and world > 1:
+        nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
+    for s, j, calls in sched:
+        reqs, k_nxt, v_nxt = [], None, None
+        if s + 1 < world:
+            k_nxt, v_nxt = torch.empty_like(k_cur), torch.empty_like(v_cur)
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, k_cur, nxt, group), dist.P2POp(dist.isend, v_cur, nxt, group),
+                                           dist.P2POp(dist.irecv, k_nxt, prv, group), dist.P2POp(dist.irecv, v_nxt, prv, group)])
+        for ci, (qp, kp, mode) in enumerate(calls):
+            o_s, lse_s = attn_fn(part(q, qp), part(k_cur, kp), part(v_cur, kp), tensor_layout=tensor_layout,
+                                 is_causal=(mode == "causal"), sm_scale=sm_scale, return_lse=True, **kwargs)
+            for hi_idx, n in enumerate(("lo", "hi")):
+                if qp not in ("all", n):
+                    continue
+                o_n = o_s if qp != "all" else o_s.narrow(dim, hi_idx * c, c)
+                l_n = lse_s if qp != "all" else lse_s.narrow(2, hi_idx * c, c)
+                merge_fn(acc[n], lse[n], o_n, l_n, tensor_layout=tensor_layout, first=((s, ci) == touches[n][0]),
+                         out=out.narrow(dim, hi_idx * c, c) if (s, ci) == touches[n][-1] else None)
+        for r in reqs:
+            r.wait()
+        if k_nxt is not None:
+            k_cur, v_cur = k_nxt, v_nxt
+    return (out, torch.cat([lse["lo"], lse["hi"]], dim=2)) if return_lse else out
+
+
 def ring_sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group=None, tensor_layout: str = "HND",
                   is_causal: bool = False, sm_scale: Optional[float] = None, return_lse: bool = False,
-                  attn_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None, **kwargs):
+                  attn_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None,
+                  shard_order: str = "contiguous", **kwargs):
     """Attention over a sequence sharded across the ranks of ``group`` (see the module docstring).
 
     ``attn_fn(q, k, v, tensor_layout=, is_causal=, sm_scale=, return_lse=True, **kwargs) -> (o, lse)`` defaults to
-    ``sageattn``; ``merge_fn`` defaults to :func:`merge_states` (both are seams for host-logic tests)."""
+    ``sageattn``; ``merge_fn`` defaults to :func:`merge_states` (both are seams for host-logic tests).
+    ``shard_order``: "contiguous", or "zigzag" (inputs sharded with :func:`zigzag_shard`; only changes the causal case,
+    without a mask the two orders do the same work)."""
     import torch.distributed as dist
     from .core import sageattn
     attn_fn = attn_fn or sageattn
     merge_fn = merge_fn or merge_states
+    assert shard_order in ("contiguous", "zigzag")
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     B, H, L, D, _, _, _ = _dims(q, tensor_layout)
     if sm_scale is None:
         sm_scale = D ** -0.5
+    if shard_order == "zigzag" and is_causal:
+        return _ring_zigzag_causal(q, k, v, group, tensor_layout, sm_scale, return_lse, attn_fn, merge_fn, world, rank, kwargs)
 
     sched = shard_schedule(rank, world, is_causal)
     active = [s for s, _, mode in sched if mode != "skip"]

@@ -51,6 +51,47 @@ def test_two_rank_ring_equals_full_attention(tmp_path, layout, causal):
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
+def _zz_worker(rank, world, port, layout, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    B, Hq, Hkv, L, D = 1, 4, 2, 64 * 2 * world, 64
+    q, k, v = torch.randn(B, Hq, L, D).half(), torch.randn(B, Hkv, L, D).half(), torch.randn(B, Hkv, L, D).half()
+    full_o, full_lse = util.attn_with_lse_f32(q, k, v, is_causal=True)
+    if layout == "NHD":
+        q, k, v, full_o = (x.transpose(1, 2).contiguous() for x in (q, k, v, full_o))
+    qs, ks, vs = (ring.zigzag_shard(x, rank, world, layout) for x in (q, k, v))
+    o, lse = ring.ring_sageattn(qs, ks, vs, tensor_layout=layout, is_causal=True, return_lse=True, shard_order="zigzag",
+                                attn_fn=util.attn_with_lse_f32, merge_fn=util.merge_states_torch)
+    want = ring.zigzag_shard(full_o, rank, world, layout)
+    want_lse = ring.zigzag_shard(full_lse.unsqueeze(-1), rank, world, "HND").squeeze(-1)
+    assert o.shape == qs.shape and (o.float() - want.float()).abs().max().item() <= 2e-3
+    assert (lse - want_lse).abs().max().item() <= 1e-4
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,layout", [(2, "HND"), (3, "NHD")])
+def test_zigzag_ring_equals_full_causal_attention(tmp_path, world, layout):
+    mp.spawn(_zz_worker, args=(world, _free_port(), layout, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_zigzag_schedule_is_balanced():
+    for w in (1, 2, 4, 8):
+        work = []
+        for r in range(w):
+            tot = 0.0
+            for _, _, calls in ring.zigzag_schedule(r, w):
+                for qp, kp, mode in calls:
+                    nq, nk = (2 if qp == "all" else 1), (2 if kp == "all" else 1)
+                    tot += nq * nk * (0.5 if mode == "causal" else 1.0)
+            work.append(tot)
+        assert max(work) == min(work) == 2.0 * w, work            # 2 c^2 per step on every rank
+
+
 def test_shard_schedule():
     assert ring.shard_schedule(0, 1, True) == [(0, 0, "causal")]
     assert ring.shard_schedule(2, 4, False) == [(0, 2, "full"), (1, 1, "full"), (2, 0, "full"), (3, 3, "full")]
