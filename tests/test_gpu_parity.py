@@ -690,3 +690,25 @@ def test_fused_q_quant_is_bit_identical_to_the_separate_quantiser(shape, dt, lay
         qkv = torch.stack([qd, qd, qd], dim=2)                       # [B, L, 3, H, D]
         o2 = sa.sageattn_qk_int8_pv_fp8_cuda(qkv[:, :, 1], kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp32")
         assert torch.equal(o2, o0)
+
+
+def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():
+    import time
+    from sageattention_amd.graph import GraphedSageAttn
+    q, k, v = (t.to(DEV) for t in rand_qkv(1, 8, 8, 256, 256, 128, 1, seed=9))
+    ga = GraphedSageAttn(q, k, v, is_causal=True, return_lse=True)
+    q2, k2, v2 = (t.to(DEV) for t in rand_qkv(1, 8, 8, 256, 256, 128, 1, seed=10))
+    o, lse = ga(q2, k2, v2)
+    want_o, want_lse = sa.sageattn(q2, k2, v2, is_causal=True, return_lse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o, want_o) and torch.equal(lse, want_lse)
+    def host_us(fn, n=200):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return dt / n * 1e6
+    eager, graphed = host_us(lambda: sa.sageattn(q2, k2, v2, is_causal=True, return_lse=True)), host_us(ga.replay)
+    REPORT["graph/host_us_per_call"] = dict(eager=eager, graphed=graphed)
+    assert graphed < eager
