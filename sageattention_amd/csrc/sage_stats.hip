@@ -28,15 +28,28 @@ stats_partial_kernel(const StatsParams p)
 #pragma unroll
     for (int j = 0; j < 8; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; sm[j] = 0.0f; }
     const int end = min(p.L, slab * kStatsSlab + kStatsSlab);
-    for (int r = slab * kStatsSlab + r0; r < end; r += RPI) {
-        const v4u raw = *reinterpret_cast<const v4u *>(x + (long)r * p.x_sl + c8);
+    // eight independent 16-byte loads in flight per thread: with one load per thread the 1024-workgroup grid keeps
+    // only ~4 MB in flight chip-wide, half of what a cold HBM read stream needs; rows are still accumulated in order
+    constexpr int UNR = 8;
+    for (int r = slab * kStatsSlab + r0; r < end; r += UNR * RPI) {
+        v4u raw[UNR];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const unsigned w = raw[j >> 1];
-            const float f = ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
-            mx[j] = fmaxf(mx[j], f);
-            mn[j] = fminf(mn[j], f);
-            sm[j] += f;
+        for (int u = 0; u < UNR; u++) {
+            const int rr = r + u * RPI;
+            raw[u] = *reinterpret_cast<const v4u *>(x + (long)(rr < end ? rr : r) * p.x_sl + c8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (r + u * RPI < end) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned w = raw[u][j >> 1];
+                    const float f = ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                    mx[j] = fmaxf(mx[j], f);
+                    mn[j] = fminf(mn[j], f);
+                    sm[j] += f;
+                }
+            }
         }
     }
 #pragma unroll
