@@ -685,6 +685,11 @@ def test_fused_q_quant_is_bit_identical_to_the_separate_quantiser(shape, dt, lay
                                              fuse_q_quant=False)
     torch.cuda.synchronize()
     assert torch.equal(o1, o0) and torch.equal(l1, l0)
+    # without K smoothing, and with the fused v_mean epilogue (smooth_v needs the single-level kernel -> unfused route only)
+    o3 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp16", smooth_k=False)
+    o4 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, tensor_layout=layout, is_causal=causal, pv_accum_dtype="fp32+fp16", smooth_k=False,
+                                         fuse_q_quant=False)
+    assert torch.equal(o3, o4)
     # a strided q view (fused QKV projection output) goes through the fused kernel without a copy
     if layout == "NHD":
         qkv = torch.stack([qd, qd, qd], dim=2)                       # [B, L, 3, H, D]
