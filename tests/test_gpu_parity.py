@@ -717,3 +717,19 @@ def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():
     eager, graphed = host_us(lambda: sa.sageattn(q2, k2, v2, is_causal=True, return_lse=True)), host_us(ga.replay)
     REPORT["graph/host_us_per_call"] = dict(eager=eager, graphed=graphed)
     assert graphed < eager
+
+
+def test_custom_ops_pass_opcheck():
+    """torch.library.opcheck on the two registered ops: schema (mutates `output` only), fake-tensor kernel agreement."""
+    from sageattention_amd import _cabi, ops
+    q, k, v = (t.to(DEV) for t in rand_qkv(1, 2, 2, 256, 192, 128, 0, seed=23))
+    km = sq.channel_mean(k)
+    q8, qs, k8, ks = sq.per_thread_int8(q, k, km)
+    img8, vs, _ = sq.per_channel_fp8(v)
+    img16 = sq.prep_v_fp16(v)
+    o = torch.empty_like(q)
+    for return_lse in (0, 1):
+        torch.library.opcheck(ops.qk_int8_sv_f8_attn, (q8, k8, img8, o, qs, ks, vs, None, 1, 1, _cabi.GRAN_PER_THREAD, 32, 0.1275, _cabi.PV_ACCUM_TWO_LEVEL, return_lse),
+                              test_utils=("test_schema", "test_faketensor"))
+        torch.library.opcheck(ops.qk_int8_sv_f16_attn, (q8, k8, img16, o, qs, ks, None, 1, 0, _cabi.GRAN_PER_THREAD, 32, 0.1275, _cabi.PV_ACCUM_SINGLE, return_lse),
+                              test_utils=("test_schema", "test_faketensor"))
