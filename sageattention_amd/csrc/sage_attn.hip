@@ -51,6 +51,25 @@
 #define SAGE_NH_F8 1
 #endif
 
+#ifndef SAGE_MAGIC      // int32 scores carry the float bias 0x4B400000 (1.5 * 2^23) from the MFMA's C operand: one exact
+#define SAGE_MAGIC 0    // v_sub_f32 replaces v_cvt_f32_i32 (|s| <= 128 * 128 * 128 < 2^22 for D <= 128: bit-identical values)
+#endif
+#ifndef SAGE_LAZY       // two-level fold only on tiles where some row maximum of the wave moved (alpha != 1); otherwise the
+#define SAGE_LAZY 0     // tile product accumulates straight into O through the MFMA's FP32 C operand
+#endif
+#ifndef SAGE_LAZY1      // experiment: single-level accumulation skips the O rescale on tiles where no row maximum moved
+#define SAGE_LAZY1 0
+#endif
+#ifndef SAGE_FORCE_SINGLE   // experiment: run two-level requests on the single-level instantiation
+#define SAGE_FORCE_SINGLE 0
+#endif
+#ifndef SAGE_QKNOP      // experiment: s_nop 7 x N after every QK^T MFMA of the steady iteration
+#define SAGE_QKNOP 0
+#endif
+#ifndef SAGE_PVNOP      // experiment: s_nop 7 x N after every PV MFMA
+#define SAGE_PVNOP 0
+#endif
+
 #ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow: 3 (<= 168 VGPRs,
                         // +3.5% measured) wherever that does not spill, i.e. everything except FP16 PV at D=128 and FP8 single-level per-thread
 #define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) ((MASK) != 0 ? 2 : ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2))
@@ -73,6 +92,27 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 
 // c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+// raw QK^T accumulator -> float score.  With SAGE_MAGIC the accumulator was started at the bit pattern of 1.5 * 2^23, so
+// reinterpreting it as a float gives 12582912 + s exactly and one subtraction recovers s (same value as the conversion).
+constexpr int kSInit = SAGE_MAGIC ? 0x4B400000 : 0;
+__device__ __forceinline__ float sfl(int x)
+{
+#if SAGE_MAGIC
+    return __int_as_float(x) - 12582912.0f;
+#else
+    return (float)x;
+#endif
+}
+template <int N> __device__ __forceinline__ void nop7()
+{
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("s_nop 7");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue
 // ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
@@ -457,18 +497,20 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                 for (int sb = 0; sb < NS; sb++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) s[sb][i] = 0;
+                    for (int i = 0; i < 16; i++) s[sb][i] = kSInit;
 #pragma unroll
                 for (int kk = 0; kk < C::KSTEPS; kk++)
 #pragma unroll
-                    for (int sb = 0; sb < NS; sb++)
+                    for (int sb = 0; sb < NS; sb++) {
                         s[sb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
+                        nop7<SAGE_QKNOP>();
+                    }
             } else
 #endif
 #pragma unroll
             for (int sb = 0; sb < NS; sb++) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) s[sb][i] = 0;
+                for (int i = 0; i < 16; i++) s[sb][i] = kSInit;
                 if (STEADY || sb < 2 * nact) {
                     const int krow = sb * 32 + n;
 #pragma unroll
@@ -504,8 +546,8 @@ sage_attn_kernel(const AttnParams p)
                             if (KTHREAD && (i & 2)) mx1 = max(mx1, s[2 * hh + u][i]);
                             else mx0 = max(mx0, s[2 * hh + u][i]);
                         }
-                    mxc = fmaxf(mxc, (float)mx0 * cs[hh][0]);
-                    if (KTHREAD) mxc = fmaxf(mxc, (float)mx1 * cs[hh][1]);
+                    mxc = fmaxf(mxc, sfl(mx0) * cs[hh][0]);
+                    if (KTHREAD) mxc = fmaxf(mxc, sfl(mx1) * cs[hh][1]);
                 }
                 m_new = fmaxf(m_run, pair_max(mxc) - OFF);
             } else {
@@ -518,8 +560,8 @@ sage_attn_kernel(const AttnParams p)
                             const float cc = cs[sb >> 1][(KTHREAD && (i & 2)) ? 1 : 0];
                             const int key = it * KT + sb * 32 + crow(i, g);
                             const bool ok = (key < Lk) && (!CAUSAL || key <= my_row);
-                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? (float)s[sb][i] * cc : 0.0f) + mk[sb][i]);
-                            else mx = fmaxf(mx, ok ? (float)s[sb][i] * cc : -INFINITY);
+                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i]);
+                            else mx = fmaxf(mx, ok ? sfl(s[sb][i]) * cc : -INFINITY);
                         }
                     }
                 m_new = fmaxf(m_run, pair_max(mx) - OFF);
@@ -527,10 +569,15 @@ sage_attn_kernel(const AttnParams p)
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             if (!TWO_LEVEL) {
+#if SAGE_LAZY1
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0)
+#endif
+                {
 #pragma unroll
-                for (int dt = 0; dt < C::DT; dt++)
+                    for (int dt = 0; dt < C::DT; dt++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+                        for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+                }
             }
 
             // P for chunk c (16 keys) of half hh = registers 8u..8u+7 of S^T tile 2hh + (c>>1):
@@ -545,9 +592,9 @@ sage_attn_kernel(const AttnParams p)
                     float v;
                     if constexpr (MASK != 0) {
                         const int key = it * KT + sb * 32 + crow(i, g);
-                        v = __builtin_amdgcn_exp2f(((key < Lk) ? (float)s[sb][i] * cc : 0.0f) + mk[sb][i] - m_new);
+                        v = __builtin_amdgcn_exp2f(((key < Lk) ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i] - m_new);
                     } else {
-                        v = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[sb][i], cc, -m_new));
+                        v = __builtin_amdgcn_exp2f(__builtin_fmaf(sfl(s[sb][i]), cc, -m_new));
                         if constexpr (decltype(masked)::value) {
                             const int key = it * KT + sb * 32 + crow(i, g);
                             const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= my_row);
@@ -579,40 +626,47 @@ sage_attn_kernel(const AttnParams p)
                 if (full) build_p(std::false_type{});
                 else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;      // lane-partial; the pair is summed in the epilogue
+                auto pv = [&](auto fold_tag) {
+                    constexpr bool FOLD = decltype(fold_tag)::value;     // tile product from zero, then O = O * alpha + T
 #pragma unroll
-                for (int dt = 0; dt < C::DT; dt++) {
-                    const int drow = dt * 32 + n;
-                    v16f acc;
-                    if (TWO_LEVEL) {
+                    for (int dt = 0; dt < C::DT; dt++) {
+                        const int drow = dt * 32 + n;
+                        v16f acc;
+                        if (FOLD) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-                    } else acc = o[dt];
+                            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+                        } else acc = o[dt];
 #pragma unroll
-                    for (int hh = 0; hh < NH; hh++) {
-                        if (STEADY || hh < nact) {
-                            const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
-                            const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                            const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
+                        for (int hh = 0; hh < NH; hh++) {
+                            if (STEADY || hh < nact) {
+                                const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
+                                const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
+                                const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
 #if SAGE_MXPV
-                            // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0)
-                            const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
-                            const v8i bv = {pw[hh][0], pw[hh][1], pw[hh][2], pw[hh][3], pw[hh][4], pw[hh][5], pw[hh][6], pw[hh][7]};
-                            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                                // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0)
+                                const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
+                                const v8i bv = {pw[hh][0], pw[hh][1], pw[hh][2], pw[hh][3], pw[hh][4], pw[hh][5], pw[hh][6], pw[hh][7]};
+                                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 #else
 #define SAGE_L(lo, hi) ((long)(((unsigned long)(unsigned)(hi) << 32) | (unsigned long)(unsigned)(lo)))
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[0], va[1]), SAGE_L(pw[hh][0], pw[hh][1]), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[2], va[3]), SAGE_L(pw[hh][2], pw[hh][3]), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[0], vb[1]), SAGE_L(pw[hh][4], pw[hh][5]), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[2], vb[3]), SAGE_L(pw[hh][6], pw[hh][7]), acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[0], va[1]), SAGE_L(pw[hh][0], pw[hh][1]), acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[2], va[3]), SAGE_L(pw[hh][2], pw[hh][3]), acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[0], vb[1]), SAGE_L(pw[hh][4], pw[hh][5]), acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[2], vb[3]), SAGE_L(pw[hh][6], pw[hh][7]), acc, 0, 0, 0);
 #undef SAGE_L
 #endif
+                                nop7<SAGE_PVNOP>();
+                            }
                         }
-                    }
-                    if (TWO_LEVEL) {
+                        if (FOLD) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
-                    } else o[dt] = acc;
-                }
+                            for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
+                        } else o[dt] = acc;
+                    }
+                };
+                if constexpr (!TWO_LEVEL) pv(std::false_type{});
+                else if (SAGE_LAZY && __builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) pv(std::false_type{});
+                else pv(std::true_type{});
             } else {
                 v8h pb[NH][4];
                 auto build_p = [&](auto masked) {
@@ -629,30 +683,36 @@ sage_attn_kernel(const AttnParams p)
                 if (full) build_p(std::false_type{});
                 else build_p(std::true_type{});
                 l_run = l_run * alpha + rs;
+                auto pv = [&](auto fold_tag) {
+                    constexpr bool FOLD = decltype(fold_tag)::value;
 #pragma unroll
-                for (int dt = 0; dt < C::DT; dt++) {
-                    const int drow = dt * 32 + n;
-                    v16f acc;
-                    if (TWO_LEVEL) {
+                    for (int dt = 0; dt < C::DT; dt++) {
+                        const int drow = dt * 32 + n;
+                        v16f acc;
+                        if (FOLD) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-                    } else acc = o[dt];
+                            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+                        } else acc = o[dt];
 #pragma unroll
-                    for (int hh = 0; hh < NH; hh++) {
-                        if (STEADY || hh < nact) {
-                            const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
+                        for (int hh = 0; hh < NH; hh++) {
+                            if (STEADY || hh < nact) {
+                                const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
 #pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const v8h a = *reinterpret_cast<const v8h *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[hh][c], acc, 0, 0, 0);
+                                for (int c = 0; c < 4; c++) {
+                                    const v8h a = *reinterpret_cast<const v8h *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[hh][c], acc, 0, 0, 0);
+                                }
                             }
                         }
-                    }
-                    if (TWO_LEVEL) {
+                        if (FOLD) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
-                    } else o[dt] = acc;
-                }
+                            for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
+                        } else o[dt] = acc;
+                    }
+                };
+                if constexpr (!TWO_LEVEL) pv(std::false_type{});
+                else if (SAGE_LAZY && __builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) pv(std::false_type{});
+                else pv(std::true_type{});
             }
         }
 
@@ -748,27 +808,45 @@ sage_attn_kernel(const AttnParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
-static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
+// One launch path for every instantiation: the > 64 KiB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize)
+// is issued once per instantiation and device, not per launch.
+template <typename Kern>
+static hipError_t launch_kernel(Kern kern, int lds, const AttnParams &p, int nwork, hipStream_t stream)
 {
-    using C = TileCfg<D, PV_FP8, NH>;
-    auto kern = sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>;
-#ifdef SAGE_LDS_MIN_BYTES   // experiments: cap workgroups per CU through the LDS budget
-    constexpr int lds = C::LDS_BYTES > SAGE_LDS_MIN_BYTES ? C::LDS_BYTES : SAGE_LDS_MIN_BYTES;
-#else
-    constexpr int lds = C::LDS_BYTES;
-#endif
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        static thread_local unsigned long long done_mask = 0;      // bit per device ordinal (thread-local: no locking needed)
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            done_mask |= bit;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
+template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
+static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
+{
+    using C = TileCfg<D, PV_FP8, NH>;
+#ifdef SAGE_LDS_MIN_BYTES   // experiments: cap workgroups per CU through the LDS budget
+    constexpr int lds = C::LDS_BYTES > SAGE_LDS_MIN_BYTES ? C::LDS_BYTES : SAGE_LDS_MIN_BYTES;
+#else
+    constexpr int lds = C::LDS_BYTES;
+#endif
+    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>, lds, p, nwork, stream);
+}
+
 template <int D, bool PV_FP8, int NH>
 static hipError_t launch_d(const AttnParams &p, int nwork, bool causal, bool kthread, bool two_level, hipStream_t s)
 {
+#if SAGE_FORCE_SINGLE
+    two_level = false;
+#endif
 #define SAGE_CASE(C_, K_, T_) if (causal == C_ && kthread == K_ && two_level == T_) return launch_one<D, PV_FP8, C_, K_, T_, NH>(p, nwork, s);
     SAGE_CASE(false, false, false) SAGE_CASE(false, false, true)
     SAGE_CASE(true, false, false)  SAGE_CASE(true, false, true)
@@ -782,18 +860,14 @@ template <int D, int MASK>
 static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stream)
 {
     using C = TileCfg<D, false, 1>;
-    auto kern = sage_attn_kernel<D, false, false, false, true, 1, MASK>;
-    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
-    return hipGetLastError();
+    return launch_kernel(sage_attn_kernel<D, false, false, false, true, 1, MASK>, C::LDS_BYTES, p, nwork, stream);
 }
 
 template <int D, bool CAUSAL, int QF>
 static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t stream)
 {
     using C = TileCfg<D, true, SAGE_NH_F8>;
-    auto kern = sage_attn_kernel<D, true, CAUSAL, true, true, SAGE_NH_F8, 0, QF>;
-    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), C::LDS_BYTES, stream, p);
-    return hipGetLastError();
+    return launch_kernel(sage_attn_kernel<D, true, CAUSAL, true, true, SAGE_NH_F8, 0, QF>, C::LDS_BYTES, p, nwork, stream);
 }
 
 // FP8 PV, two-level accumulation, per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel

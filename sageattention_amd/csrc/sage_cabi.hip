@@ -337,7 +337,7 @@ SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, 
 {
     SAGE_REQUIRE(o_acc && lse_acc && o_new && lse_new, "null tensor pointer");
     SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem (B=%d H=%d L=%d)", B, H, L);
-    SAGE_REQUIRE(D > 0 && D % 8 == 0, "head_dim must be a positive multiple of 8 (got %d)", D);
+    SAGE_REQUIRE(D > 0 && D % 8 == 0 && D <= 512, "head_dim must be a positive multiple of 8, at most 512 (got %d)", D);
     SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
     SAGE_REQUIRE(aligned16(o_acc) && aligned16(o_new) && (o_out == nullptr || aligned16(o_out)), "o tensors must be 16-byte aligned");
     SAGE_REQUIRE(n_sb % 8 == 0 && n_sh % 8 == 0 && n_sl % 8 == 0, "o_new strides must be multiples of 8 elements");

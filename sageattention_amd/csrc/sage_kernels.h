@@ -111,6 +111,7 @@ struct MergeParams {
     long o_sb, o_sh, o_sl;    // o_out strides
     int dtype;
     int first;                // 1: initialise the running state from (o_new, lse_new)
+    int cpr_pad;              // set by launch_merge_states: lanes per row (power of two >= D/8, <= 64)
 };
 hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream);
 

@@ -17,11 +17,16 @@ template <int DT>
 __global__ void __launch_bounds__(256)
 merge_states_kernel(const MergeParams p)
 {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    // A row is owned by `cpr_pad` consecutive lanes (cpr rounded up to a power of two <= 64), so all threads of a row
+    // sit in ONE wave: every lane's read of lse_acc[row] is issued before the c8 == 0 lane's write of the merged value
+    // (wave-lockstep program order).  Spreading a row over waves / workgroups (the round-1 mapping for D = 96, 80, ...)
+    // let a later wave read the already-merged lse.
     const int cpr = p.D / 8;                        // 8-channel chunks per row
-    const long row = t / cpr;
-    if (row >= (long)p.B * p.H * p.L) return;
-    const int c8 = (int)(t - row * cpr) * 8;
+    const int cpr_pad = p.cpr_pad;
+    const long row = (long)blockIdx.x * (256 / cpr_pad) + threadIdx.x / cpr_pad;
+    const int c = threadIdx.x % cpr_pad;
+    if (row >= (long)p.B * p.H * p.L || c >= cpr) return;
+    const int c8 = c * 8;
     const int l = (int)(row % p.L);
     const long bh = row / p.L;
     const int h = (int)(bh % p.H), b = (int)(bh / p.H);
@@ -72,11 +77,16 @@ merge_states_kernel(const MergeParams p)
 
 hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream)
 {
-    const long threads = (long)p.B * p.H * p.L * (p.D / 8);
-    if (threads <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((threads + 255) / 256));
-    if (p.dtype == DT_F16) hipLaunchKernelGGL(merge_states_kernel<DT_F16>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(merge_states_kernel<DT_BF16>, grid, dim3(256), 0, stream, p);
+    const long rows = (long)p.B * p.H * p.L;
+    if (rows <= 0) return hipSuccess;
+    MergeParams q = p;
+    q.cpr_pad = 1;
+    while (q.cpr_pad < p.D / 8) q.cpr_pad *= 2;
+    if (q.cpr_pad > 64) return hipErrorInvalidValue;          // head_dim <= 512 (checked by the C ABI)
+    const long rpb = 256 / q.cpr_pad;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (p.dtype == DT_F16) hipLaunchKernelGGL(merge_states_kernel<DT_F16>, grid, dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(merge_states_kernel<DT_BF16>, grid, dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
