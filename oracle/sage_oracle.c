@@ -219,7 +219,10 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
     /* mean (nullable, [B,H,D]): smooth_v -- subtracted before scaling; amax becomes
      * max(|max - mean|, |min - mean|) (fused.cu:383-385).  The reference computes the mean itself as
      * sum / ceil16(L) (fused.cu:335,381); it is an input here so that the checker and the checked
-     * kernel quantise against the very same mean. */
+     * kernel quantise against the very same mean.
+     * MeanScaleKernel reads ceil16(L) tokens of the ZERO-PADDED transpose (fused.cu:335-357, padding written
+     * by TransposePadPermuteKernel fused.cu:283-286), so when L % 16 != 0 the zeros take part in max and min:
+     * immaterial for the plain amax, but with smooth_v the amax includes |0 - mean|. */
     for (int b = 0; b < B; b++)
         for (int h = 0; h < H; h++) {
             const uint16_t *vb = v + ((size_t)(b * H + h) * L) * D;
@@ -233,6 +236,7 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
                     mx = fmaxf(mx, f);
                     mn = fminf(mn, f);
                 }
+                if (L % 16) { mx = fmaxf(mx, 0.0f); mn = fminf(mn, 0.0f); }
                 float amax = fmaxf(fabsf(mx - mu), fabsf(mn - mu));
                 sb[d] = amax / scale_max;
                 float recp = amax > 0.0f ? scale_max / amax : 0.0f;
@@ -338,12 +342,17 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                     for (int i = 0; i < rows; i++) {
                         const int8_t *qr = qp + (size_t)(r0 + i) * D;
                         const float qsc = qs[q_sidx[r0 + i]];
-                        float mx = NEG_BIG;
+                        float mx = NEG_BIG;       /* non-fused: max score; fused: max of (score - offset) */
                         float dotf[BN], ccj[BN];
                         /* pv_mode 0 restates the Triton kernel literally: qk = dot * (q_scale*k_scale), then
-                         * qk - m (attn_qk_int8_per_block.py:41,53-55).  The other modes restate the CUDA kernels'
-                         * update_mdo: one FMA per score, exp2(fma(s, scale, -m)) (attn_utils.cuh:445-449), with the
-                         * per-score scale formed as (q_scale * sm_scale*log2e) * k_scale. */
+                         * qk - m (attn_qk_int8_per_block.py:41,53-55).  The other modes restate the CUDA kernels:
+                         *   dequant_scale = q_scale * k_scale;  sm_scale' = (sm_scale*log2e) * dequant_scale
+                         *                                              (qk_int_sv_f8_cuda_sm89.cuh:263-266,334-335)
+                         *   m_temp = fma(max raw score, sm_scale', -offset)      (attn_utils.cuh:372-384)
+                         *   P = exp2(fma(raw score, sm_scale', -m))              (attn_utils.cuh:445-449)
+                         * A reference thread holds scores of ONE key-scale group: it takes the maximum of the raw
+                         * scores, applies its group's FMA, and the results are max-reduced across threads.  FMA with a
+                         * non-negative scale is monotone, so max_j fma(raw_j, scale_j, -offset) is the same number. */
                         const int fused = (pv_mode != 0) && !masked;
                         for (int j = 0; j < BN; j++) {
                             float s = NEG_BIG;
@@ -354,8 +363,8 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                                 for (int d = 0; d < D; d++) dot += (int32_t)qr[d] * (int32_t)kr[d];
                                 if (fused) {
                                     dotf[j] = (float)dot;
-                                    ccj[j] = (qsc * c) * ks[k_sidx[n0 + j]];
-                                    s = dotf[j] * ccj[j];
+                                    ccj[j] = c * (qsc * ks[k_sidx[n0 + j]]);
+                                    s = fmaf(dotf[j], ccj[j], -off);
                                 } else {
                                     s = (float)dot * (qsc * ks[k_sidx[n0 + j]]) * c;
                                 }
@@ -365,7 +374,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                             p[i][j] = s;
                             mx = fmaxf(mx, s);
                         }
-                        float m_new = fmaxf(m[i], mx - off);
+                        float m_new = fmaxf(m[i], fused ? mx : mx - off);
                         float alpha = exp2f(m[i] - m_new);
                         float rs = 0.0f;
                         for (int j = 0; j < BN; j++) {

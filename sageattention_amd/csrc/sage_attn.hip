@@ -226,7 +226,7 @@ sage_attn_kernel(const AttnParams p)
         else if (p.q_gran == QG_PER_WARP32) slot = rin >> 5;
         else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
         else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
-        qsc = qs_ptr[slot * qs_stride] * p.sm_scale_log2;
+        qsc = qs_ptr[slot * qs_stride];
     } else {
         // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
         // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
@@ -256,7 +256,7 @@ sage_attn_kernel(const AttnParams p)
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         const float sc = quant_scale(amax, QS_TRITON_THREAD);
         const float y = quant_recip(sc);
-        qsc = sc * p.sm_scale_log2;
+        qsc = sc;
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             int q8[16];
@@ -521,12 +521,13 @@ sage_attn_kernel(const AttnParams p)
                 }
             }
 
-            // ---- scales: c multiplies the raw int32 score into the log2 domain ----
+            // ---- scales: c multiplies the raw int32 score into the log2 domain, formed in the reference's order
+            //      sm_scale*log2e * (q_scale * k_scale)  (qk_int_sv_f8_cuda_sm89.cuh:263-266,334-335) ----
             float cs[NH][2];
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) {
-                cs[hh][0] = qsc * ksc[hh][0];
-                cs[hh][1] = qsc * ksc[hh][1];
+                cs[hh][0] = p.sm_scale_log2 * (qsc * ksc[hh][0]);
+                cs[hh][1] = KTHREAD ? p.sm_scale_log2 * (qsc * ksc[hh][1]) : cs[hh][0];
             }
 
             // ---- online softmax over the iteration's keys ----
@@ -546,10 +547,11 @@ sage_attn_kernel(const AttnParams p)
                             if (KTHREAD && (i & 2)) mx1 = max(mx1, s[2 * hh + u][i]);
                             else mx0 = max(mx0, s[2 * hh + u][i]);
                         }
-                    mxc = fmaxf(mxc, sfl(mx0) * cs[hh][0]);
-                    if (KTHREAD) mxc = fmaxf(mxc, sfl(mx1) * cs[hh][1]);
+                    // m_temp = fma(max raw score, scale, -offset)  (attn_utils.cuh:372-384)
+                    mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx0), cs[hh][0], -OFF));
+                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[hh][1], -OFF));
                 }
-                m_new = fmaxf(m_run, pair_max(mxc) - OFF);
+                m_new = fmaxf(m_run, pair_max(mxc));
             } else {
                 float mx = -INFINITY;
 #pragma unroll
@@ -560,11 +562,11 @@ sage_attn_kernel(const AttnParams p)
                             const float cc = cs[sb >> 1][(KTHREAD && (i & 2)) ? 1 : 0];
                             const int key = it * KT + sb * 32 + crow(i, g);
                             const bool ok = (key < Lk) && (!CAUSAL || key <= my_row);
-                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i]);
-                            else mx = fmaxf(mx, ok ? sfl(s[sb][i]) * cc : -INFINITY);
+                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i] - OFF);
+                            else mx = fmaxf(mx, ok ? __builtin_fmaf(sfl(s[sb][i]), cc, -OFF) : -INFINITY);
                         }
                     }
-                m_new = fmaxf(m_run, pair_max(mx) - OFF);
+                m_new = fmaxf(m_run, pair_max(mx));
             }
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;

@@ -61,12 +61,17 @@ prep_v_kernel(const PrepVParams p)
         //   plain   : amax = max(|max|, |min|)                              (fused.cu:388)
         //   smooth_v: mean = sum / ceil16(L)  (the reference divides by the 16-padded length,
         //             fused.cu:335,381), amax = max(|max - mean|, |min - mean|)  (fused.cu:383-385)
+        //   The reference takes max/min over the ceil16(L) tokens of its zero-padded transpose (fused.cu:335-357), so
+        //   for L % 16 != 0 the padding zeros take part: irrelevant for the plain amax, part of the smooth_v amax.
         const float *st = p.stats + ((long)b * p.H + h) * 3 * D;
         const bool smooth = p.v_mean != nullptr;
         const float lpad = (float)((L + 15) / 16 * 16);
+        const bool padded = (L & 15) != 0;
         auto chan = [&](int d, float &mean, float &am) {
             mean = smooth ? st[2 * D + d] / lpad : 0.0f;
-            am = fmaxf(fabsf(st[d] - mean), fabsf(st[D + d] - mean));
+            float mx = st[d], mn = st[D + d];
+            if (padded) { mx = fmaxf(mx, 0.0f); mn = fminf(mn, 0.0f); }
+            am = fmaxf(fabsf(mx - mean), fabsf(mn - mean));
         };
         if (t == 0 && tid < D) {
             float mean, am;
