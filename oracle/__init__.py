@@ -257,8 +257,9 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
     return o, lse, aux
 
 
-def sageattn_varlen(q, k, v, dtype: int, cu_q, cu_k, *, is_causal=False, sm_scale=None, smooth_k=True):
-    """sageattn_varlen (core.py:334-448) on packed [sum L, H, D] arrays of fp16/bf16 bits."""
+def sageattn_varlen(q, k, v, dtype: int, cu_q, cu_k, *, is_causal=False, sm_scale=None, smooth_k=True, km=None):
+    """sageattn_varlen (core.py:334-448) on packed [sum L, H, D] arrays of fp16/bf16 bits.
+    km (bits [1, Hkv, D], optional): the K mean to use instead of computing it (host plumbing, as in sageattn_dense)."""
     D0 = q.shape[-1]
     q, k, v = (_pad_head_dim(t, dtype) for t in (q, k, v))
     if sm_scale is None:
@@ -266,8 +267,10 @@ def sageattn_varlen(q, k, v, dtype: int, cu_q, cu_k, *, is_causal=False, sm_scal
     vh = v if dtype == F16 else convert(to_f32(v, dtype), "f16")
     if smooth_k:   # mean over ALL packed tokens, then k - km in the input dtype (core.py:432-434)
         kf = to_f32(k, dtype)
-        km = to_f32(convert(kf.astype(np.float64).mean(axis=0, keepdims=True).astype(np.float32),
-                            "f16" if dtype == F16 else "bf16"), dtype)
+        if km is None:
+            km = convert(kf.astype(np.float64).mean(axis=0, keepdims=True).astype(np.float32),
+                         "f16" if dtype == F16 else "bf16")
+        km = to_f32(np.asarray(km).reshape(1, k.shape[1], k.shape[2]), dtype)
         k = convert(kf - km, "f16" if dtype == F16 else "bf16")
     o = np.zeros(q.shape, dtype=np.uint16)
     for b in range(len(cu_q) - 1):

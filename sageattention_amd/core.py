@@ -12,6 +12,7 @@ tensors or a missing library raise.
 """
 from __future__ import annotations
 
+import ctypes
 import warnings
 from typing import Any, Optional
 
@@ -227,14 +228,21 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     return o[..., :head_dim_og]
 
 
+def _sm_log2(sm_scale: float) -> float:
+    """sm_scale * log2(e) as the CUDA kernels form it: the Python double becomes a float kernel argument and is
+    multiplied by the fp32 constant in fp32 (`sm_scale *= math::log2e`, qk_int_sv_f8_cuda_sm89.cuh:90, math.cuh:32).
+    The product of two fp32 numbers is exact in a double, so one rounding to c_float is the fp32 product."""
+    return ctypes.c_float(ctypes.c_float(sm_scale).value * ctypes.c_float(1.44269504088896340736).value).value
+
+
 def _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale):
     """Returns (q_int8, q_scale, k_int8, k_scale, gran code, q_warp, sm_scale_log2)."""
     if qk_quant_gran == "per_warp":
         return (*per_warp_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=64),
-                _cabi.GRAN_PER_WARP, warpq, sm_scale * LOG2E)
+                _cabi.GRAN_PER_WARP, warpq, _sm_log2(sm_scale))
     if qk_quant_gran == "per_thread":
         return (*per_thread_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64),
-                _cabi.GRAN_PER_THREAD, 32, sm_scale * LOG2E)
+                _cabi.GRAN_PER_THREAD, 32, _sm_log2(sm_scale))
     # "per_block": gfx950 extension (the Triton path's granularity with the CUDA rounding)
     return (*per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout, quantization_backend="cuda"),
             _cabi.GRAN_PER_BLOCK, 128, 1.0)
@@ -303,7 +311,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         km_s = _squeeze_km(km, tensor_layout)
         k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
         v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
-        o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale * LOG2E,
+        o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
                                return_lse, v_mean=vm)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)

@@ -70,6 +70,9 @@
 #define SAGE_PVNOP 0
 #endif
 
+#ifdef SAGE_FORCE_WAVES // experiment: one waves/SIMD bound for every instantiation
+#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) SAGE_FORCE_WAVES
+#endif
 #ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow: 3 (<= 168 VGPRs,
                         // +3.5% measured) wherever that does not spill, i.e. everything except FP16 PV at D=128 and FP8 single-level per-thread
 #define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) ((MASK) != 0 ? 2 : ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2))

@@ -162,6 +162,24 @@ def varlen_case(name, lens, Hq, Hkv, D, dtype, causal, seed=0):
          meta=np.array([len(lens), Hq, Hkv, total, total, D, 0 if dtype == torch.float16 else 1, int(causal)], dtype=np.int64))
 
 
+def varlen_cross_case(name, lens_q, lens_k, Hq, Hkv, D, dtype, causal, seed=0):
+    """cu_seqlens_q != cu_seqlens_k (cross-attention-like packing; causal stays top-left aligned,
+    attn_qk_int8_per_block_causal_varlen.py)."""
+    torch.manual_seed(seed)
+    tq, tk = sum(lens_q), sum(lens_k)
+    q = torch.randn(tq, Hq, D).to(dtype)
+    k = (torch.randn(tk, Hkv, D) + 1.5 * torch.randn(1, Hkv, D)).to(dtype)
+    v = torch.randn(tk, Hkv, D).to(dtype)
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32)
+    o, aux = ref_varlen(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal)
+    save(name, q=bits(q), k=bits(k), v=bits(v), o=bits(o), cu_q=cu_q.numpy(), cu_k=cu_k.numpy(),
+         q_int8=aux["q_int8"].numpy(), q_scale=aux["q_scale"].numpy(),
+         k_int8=aux["k_int8"].numpy(), k_scale=aux["k_scale"].numpy(),
+         cu_qs=aux["cu_qs"].numpy(), cu_ks=aux["cu_ks"].numpy(),
+         meta=np.array([len(lens_q), Hq, Hkv, tq, tk, D, 0 if dtype == torch.float16 else 1, int(causal)], dtype=np.int64))
+
+
 def per_thread_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, seed=0):
     torch.manual_seed(seed)
     q = torch.randn(B, Hq, Lq, D).to(dtype)
@@ -180,6 +198,10 @@ if __name__ == "__main__":
         mask_case("mask_bool_lq300_lk333_d64_f16", 2, 4, 2, 300, 333, 64, f16, "bool", seed=8)
         mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--varlen-cross-only":
+        varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
+        varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
+        sys.exit(0)
     dense_case("c1_b1h4n512d64_f16", 1, 4, 4, 512, 512, 64, f16, False)             # BASELINE.json configs[0]
     dense_case("gqa_causal_n300d128_bf16", 1, 4, 2, 300, 300, 128, bf16, True, kbias=2.0, seed=1)
     dense_case("cross_lq200_lk333_d64_f16", 2, 2, 2, 200, 333, 64, f16, False, kbias=1.0, seed=2)
@@ -191,3 +213,5 @@ if __name__ == "__main__":
     per_thread_case("per_thread_quant_d128_f16", 1, 2, 1, 200, 150, 128, f16, seed=7)
     mask_case("mask_bool_lq300_lk333_d64_f16", 2, 4, 2, 300, 333, 64, f16, "bool", seed=8)
     mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)
+    varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
+    varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)

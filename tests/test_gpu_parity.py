@@ -550,6 +550,118 @@ def test_config4_varlen_gqa():
             assert cos >= 0.9995
 
 
+# ------------------------------------------------------------------------------------------------ BASELINE.json full sizes vs the ORACLE
+def _assert_vs_oracle(tag, got, ref_bits, dt, tol_rel=2e-3):
+    """max|o_hip - o_oracle| <= 2e-3 * max|o| + one output ulp at max|o| (the bar of the small-shape kernel tests)."""
+    ref = util.f32(ref_bits, dt)
+    assert np.isfinite(got).all()
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    rms = float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+    REPORT[f"full_vs_oracle/{tag}"] = dict(max_abs=err, max_o=scale, rel_rms=rms, elements=int(ref.size))
+    assert err <= tol_rel * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale, f"{tag}: max|diff| {err:.3e} vs max|o| {scale:.3e}"
+
+
+def test_config2_full_vs_oracle(oracle_mod):
+    """BASELINE.json configs[1], every (batch, head): sageattn_qk_int8_pv_fp16_cuda against the oracle (B2 H32 N4096 D128 causal)."""
+    q, k, v = rand_qkv(2, 32, 32, 4096, 4096, 128, 0, seed=2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(qd, kd, vd, is_causal=True, pv_accum_dtype="fp32", return_lse=True)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean(kd))
+    ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 0, is_causal=True, pv="f16",
+                                                qk_quant_gran="per_thread", return_lse=True, km=km)
+    _assert_vs_oracle("c2_f16pv_b2h32n4096d128_causal", o.float().cpu().numpy(), ref, 0)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
+
+
+def test_config3_full_vs_oracle(oracle_mod):
+    """BASELINE.json configs[2] -- the headline configuration, all 64 (batch, head) units: FP8 PV, two-level
+    accumulation, per-thread scales, bf16, B2 H32 N8192 D128 causal (the fused-Q default route)."""
+    q, k, v = rand_qkv(2, 32, 32, 8192, 8192, 128, 1, seed=3)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=True, pv_accum_dtype="fp32+fp32", return_lse=True)
+    o_default = sa.sageattn(qd, kd, vd, is_causal=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o_default, o), "sageattn() dispatches to the FP8 two-level path"
+    km = util.bits(sq.channel_mean(kd))
+    ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 1, is_causal=True, pv="f8",
+                                                qk_quant_gran="per_thread", return_lse=True, km=km)
+    _assert_vs_oracle("c3_f8pv_b2h32n8192d128_causal", o.float().cpu().numpy(), ref, 1)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_config4_full_vs_oracle(oracle_mod, causal):
+    """BASELINE.json configs[3]: sageattn_varlen, Hq=32 Hkv=8 D=128 bf16, all eight sequences 256..16384 (one ragged).
+    Causal: every head; non-causal (twice the oracle work): the first two GQA groups (8 query heads) of the full call."""
+    lens = [256, 512, 1000, 1024, 2048, 4096, 8192, 16384]
+    total = sum(lens)
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(total, 32, 128, generator=g).to(torch.bfloat16)
+    k = (torch.randn(total, 8, 128, generator=g) + torch.randn(1, 8, 128, generator=g)).to(torch.bfloat16)
+    v = torch.randn(total, 8, 128, generator=g).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = sa.sageattn_varlen(qd, kd, vd, cu.to(DEV), cu.to(DEV), max(lens), max(lens), is_causal=causal)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean_packed(kd))                      # [1, Hkv, D]: the mean over ALL packed tokens
+    hq, hk = (32, 8) if causal else (8, 2)
+    ref = oracle_mod.sageattn_varlen(util.bits(q[:, :hq]), util.bits(k[:, :hk]), util.bits(v[:, :hk]), 1, cu.numpy(), cu.numpy(),
+                                     is_causal=causal, km=np.ascontiguousarray(km[:, :hk]))
+    _assert_vs_oracle(f"c4_varlen_gqa_{'causal' if causal else 'noncausal'}", o[:, :hq].float().cpu().numpy(), ref, 1)
+
+
+def test_config5_cogvideox_shape_vs_oracle(oracle_mod):
+    """BASELINE.json configs[4]: the CogVideoX1.5-shaped drop-in call, B2 H48 N=17776 (= 277*64 + 48: a
+    ragged last tile in both dimensions) D64 bf16 non-causal through sageattn(); the oracle checks eight heads of it."""
+    B, H, N, D = 2, 48, 17776, 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, H, N, D, generator=g).to(torch.bfloat16)
+    k = (torch.randn(B, H, N, D, generator=g) + 2.0 * torch.randn(B, H, 1, D, generator=g)).to(torch.bfloat16)
+    v = torch.randn(B, H, N, D, generator=g).to(torch.bfloat16)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = sa.sageattn(qd, kd, vd, is_causal=False)
+    torch.cuda.synchronize()
+    assert o.shape == q.shape and o.dtype == torch.bfloat16 and torch.isfinite(o.float()).all()
+    hs = [0, 7, 13, 22, 31, 38, 41, 47]
+    b = 1
+    km = util.bits(sq.channel_mean(kd))[b:b + 1, hs]
+    ref, _, _ = oracle_mod.sageattn_dense(util.bits(q[b:b + 1, hs]), util.bits(k[b:b + 1, hs]), util.bits(v[b:b + 1, hs]), 1,
+                                          is_causal=False, pv="f8", qk_quant_gran="per_thread", km=np.ascontiguousarray(km))
+    _assert_vs_oracle("c5_cogvideox_b2h48n17776d64", o[b:b + 1, hs].float().cpu().numpy(), ref, 1)
+    truth = util.sdpa_f32(qd[b:b + 1, hs[:2]], kd[b:b + 1, hs[:2]], vd[b:b + 1, hs[:2]], False).cpu().numpy()
+    got = o[b:b + 1, hs[:2]].float().cpu().numpy()
+    cos, rel = util.cos_sim(got, truth), util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
+    REPORT["full/c5_cogvideox"] = dict(cos=cos, rel_rmse=rel)
+    assert cos >= 0.999 and rel <= 0.05
+
+
+@pytest.mark.parametrize("name", ["varlenx_nc_d128_bf16", "varlenx_c_d64_f16"])
+def test_varlen_cu_q_differs_from_cu_k(oracle_mod, name):
+    """cu_seqlens_q != cu_seqlens_k (per-sequence Lq != Lk, causal top-left aligned) against the reference's Triton output
+    (fixture generated by tests/golden/gen_golden.py) and against the oracle."""
+    z, (nseq, Hq, Hkv, tq, tk, D, dt, causal) = util.golden(name)
+    q, k, v = (util.from_bits(z[n], dt, DEV) for n in ("q", "k", "v"))
+    cu_q, cu_k = torch.from_numpy(z["cu_q"]).to(DEV), torch.from_numpy(z["cu_k"]).to(DEV)
+    mq, mk = int(np.diff(z["cu_q"]).max()), int(np.diff(z["cu_k"]).max())
+    o = sa.sageattn_varlen(q, k, v, cu_q, cu_k, mq, mk, is_causal=bool(causal))
+    torch.cuda.synchronize()
+    got, ref = o.float().cpu().numpy(), util.f32(z["o"], dt)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    REPORT[f"golden/{name}"] = dict(max_abs=err, max_o=scale)
+    assert err <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
+    km = util.from_bits(oracle_km_packed(z["k"], dt), dt, DEV)
+    q8, qs, k8, ks, cu_qs, cu_ks = sq.per_block_int8_varlen(q, k, cu_q, cu_k, mq, mk, km=km, sm_scale=D ** -0.5)
+    assert (cu_qs.cpu().numpy() == z["cu_qs"]).all() and (cu_ks.cpu().numpy() == z["cu_ks"]).all()
+    assert (q8.cpu().numpy() == z["q_int8"]).all() and (qs.cpu().numpy() == z["q_scale"]).all()
+    assert (k8.cpu().numpy() == z["k_int8"]).all() and (ks.cpu().numpy() == z["k_scale"]).all()
+    ref_o = oracle_mod.sageattn_varlen(z["q"], z["k"], z["v"], dt, z["cu_q"], z["cu_k"], is_causal=bool(causal),
+                                       km=util.bits(sq.channel_mean_packed(k)))
+    _assert_vs_oracle(f"varlen_cross/{name}", got, ref_o, dt)
+
+
 # ------------------------------------------------------------------------------------------------ LSE merge / ring caller
 @pytest.mark.parametrize("dt,layout,D,L", [(0, "HND", 128, 333), (1, "NHD", 64, 130), (1, "HND", 96, 17)])
 def test_merge_states_matches_formula(dt, layout, D, L):

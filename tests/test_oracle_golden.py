@@ -51,6 +51,17 @@ def test_varlen_matches_reference(oracle_mod, name):
     assert np.abs(of - rf).max() <= tol
 
 
+@pytest.mark.parametrize("name", ["varlenx_nc_d128_bf16", "varlenx_c_d64_f16"])
+def test_varlen_cu_q_differs_from_cu_k_matches_reference(oracle_mod, name):
+    """cu_seqlens_q != cu_seqlens_k (per-sequence Lq != Lk; causal top-left aligned) against the reference kernels."""
+    z, (nseq, Hq, Hkv, tq, tk, D, dt, causal) = util.golden(name)
+    assert not np.array_equal(z["cu_q"], z["cu_k"])
+    o = oracle_mod.sageattn_varlen(z["q"], z["k"], z["v"], dt, z["cu_q"], z["cu_k"], is_causal=bool(causal))
+    of, rf = util.f32(o, dt), util.f32(z["o"], dt)
+    tol = (2 ** -10 if dt == 0 else 2 ** -7) * max(1.0, float(np.abs(rf).max()))
+    assert np.abs(of - rf).max() <= tol
+
+
 @pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add")])
 def test_attn_mask_matches_reference(oracle_mod, name, kind):
     """Triton API attn_mask semantics (bool 0/-1e6 + all-False tile skip, additive float), incl. fully masked rows."""
