@@ -51,8 +51,17 @@
 #define SAGE_NH_F8 1
 #endif
 
-#ifndef SAGE_MAGIC      // int32 scores carry the float bias 0x4B400000 (1.5 * 2^23) from the MFMA's C operand: one exact
-#define SAGE_MAGIC 0    // v_sub_f32 replaces v_cvt_f32_i32 (|s| <= 128 * 128 * 128 < 2^22 for D <= 128: bit-identical values)
+#ifndef SAGE_MAGIC      // the int32 QK^T accumulators start from the bit pattern of the inline constant 1/(2 pi) = 0x3E22F983 (free as
+#define SAGE_MAGIC 1    // the MFMA's C operand): read as a float they are 1/(2 pi) + s * 2^-26 exactly, so one exact v_sub_f32 (2 cycles)
+#endif                  // replaces v_cvt_f32_i32 (4) and the 2^26 goes into the scale: bit-identical scores (see sfl below)
+#ifndef SAGE_ROT        // rotated steady-state iteration: K fragments of tile t+1 are requested before PV(t), V fragments of tile t
+#define SAGE_ROT 1      // before softmax(t), the ring barrier sits between softmax and PV (no LDS latency on the critical path)
+#endif
+#ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
+#define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
+#endif
+#ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
+#define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
 #ifndef SAGE_LAZY       // two-level fold only on tiles where some row maximum of the wave moved (alpha != 1); otherwise the
 #define SAGE_LAZY 0     // tile product accumulates straight into O through the MFMA's FP32 C operand
@@ -70,12 +79,17 @@
 #define SAGE_PVNOP 0
 #endif
 
+#ifndef SAGE_ABL        // timing ablations of the rotated steady iteration (results are garbage): bit 0 no softmax VALU, 1 no QK^T MFMAs,
+#define SAGE_ABL 0      // 2 no PV MFMAs, 3 no LDS-DMA, 4 no barrier, 5 no K ds_reads, 6 no V ds_reads, 7 no row max, 8 no exp2, 9 no fp8 pack
+#endif
 #ifdef SAGE_FORCE_WAVES // experiment: one waves/SIMD bound for every instantiation
 #define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) SAGE_FORCE_WAVES
 #endif
-#ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow: 3 (<= 168 VGPRs,
-                        // +3.5% measured) wherever that does not spill, i.e. everything except FP16 PV at D=128 and FP8 single-level per-thread
-#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) ((MASK) != 0 ? 2 : ((((PV_FP8) && ((TWO_LEVEL) || !(KTHREAD))) || (D) == 64) ? 3 : 2))
+#ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow.  The software-pipelined FP8 loop carries two
+                        // score tiles at D=128 (248 VGPRs: 2 waves; measured equal to 3 waves for the phased loop); D=64 fits 3 (167).
+                        // Phased loops: 3 (<= 168 VGPRs, +3.5% measured) wherever that does not spill.
+#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) \
+    ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : ((PV_FP8) ? ((SAGE_PIPE && SAGE_MAGIC && (!(TWO_LEVEL) || SAGE_DIRECT)) ? 2 : (((TWO_LEVEL) || !(KTHREAD)) ? 3 : 2)) : 2)))
 #endif
 
 namespace sage {
@@ -96,15 +110,32 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 // c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-// raw QK^T accumulator -> float score.  With SAGE_MAGIC the accumulator was started at the bit pattern of 1.5 * 2^23, so
-// reinterpreting it as a float gives 12582912 + s exactly and one subtraction recovers s (same value as the conversion).
-constexpr int kSInit = SAGE_MAGIC ? 0x4B400000 : 0;
+// raw QK^T accumulator -> float score (in units of kSUnit^-1).
+// 0x3E22F983 lies mid-binade ([0.125, 0.25), ulp 2^-26, mantissa field 2292099): for |s| <= 128 * 128 * 128 = 2097152 the sum
+// stays inside the binade, so bits + s is the float 1/(2 pi) + s * 2^-26, the subtraction below is exact (Sterbenz) and
+// fma(s * 2^-26, c * 2^26, -m) rounds the same real number as fma((float)s, c, -m): bit-identical to the conversion.
+constexpr int kSInit = SAGE_MAGIC ? 0x3E22F983 : 0;
+constexpr float kSUnit = SAGE_MAGIC ? 67108864.0f : 1.0f;       // 2^26: folded into the score scale
 __device__ __forceinline__ float sfl(int x)
 {
 #if SAGE_MAGIC
-    return __int_as_float(x) - 12582912.0f;
+    return __int_as_float(x) - __int_as_float(0x3E22F983);
 #else
     return (float)x;
+#endif
+}
+// first MFMA of a QK^T accumulation chain: C = kSInit as an inline constant (hipcc materialises an integer splat of
+// 0x3E22F983 in 16 VGPRs instead; the assembler encodes it as inline operand 248).  The builtin MFMAs that follow take the
+// result whole as their C operand (accumulate chain: no wait states, cdna_hip_programming.md 5.7 item 2).
+__device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
+{
+#if SAGE_MAGIC
+    v16i d;
+    asm("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, z, 0, 0, 0);
 #endif
 }
 template <int N> __device__ __forceinline__ void nop7()
@@ -498,14 +529,10 @@ sage_attn_kernel(const AttnParams p)
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int sb = 0; sb < NS; sb++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) s[sb][i] = kSInit;
-#pragma unroll
                 for (int kk = 0; kk < C::KSTEPS; kk++)
 #pragma unroll
                     for (int sb = 0; sb < NS; sb++) {
-                        s[sb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
+                        s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
                         nop7<SAGE_QKNOP>();
                     }
             } else
@@ -513,13 +540,13 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
             for (int sb = 0; sb < NS; sb++) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) s[sb][i] = kSInit;
+                for (int i = 0; i < 16; i++) s[sb][i] = 0;        // sub-tiles past the wave's last key are masked below
                 if (STEADY || sb < 2 * nact) {
                     const int krow = sb * 32 + n;
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
                         const v4i a = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                        s[sb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], s[sb], 0, 0, 0);
+                        s[sb] = kk == 0 ? mfma_i8_first(a, qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], s[sb], 0, 0, 0);
                     }
                 }
             }
@@ -529,8 +556,8 @@ sage_attn_kernel(const AttnParams p)
             float cs[NH][2];
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) {
-                cs[hh][0] = p.sm_scale_log2 * (qsc * ksc[hh][0]);
-                cs[hh][1] = KTHREAD ? p.sm_scale_log2 * (qsc * ksc[hh][1]) : cs[hh][0];
+                cs[hh][0] = (p.sm_scale_log2 * (qsc * ksc[hh][0])) * kSUnit;
+                cs[hh][1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[hh][1])) * kSUnit : cs[hh][0];
             }
 
             // ---- online softmax over the iteration's keys ----
@@ -729,6 +756,164 @@ sage_attn_kernel(const AttnParams p)
         ring_wait(more2);
         cur = nxt;
     };
+
+#if SAGE_ROT
+    // ---- rotated steady-state iteration (whole, unmasked tiles; FP8 PV; MASK == 0; NH == 1; 3-slot ring) ----------------
+    // Same arithmetic as tile_iter(steady) in a different order, so that no LDS or DMA latency sits between a wave's
+    // matrix phases:   QK^T(t)  [K fragments already in registers]
+    //                  request V fragments of tile t (first half now, second half once half of S is consumed)
+    //                  softmax(t)
+    //                  vmcnt(0) + s_barrier: tile t+1 has landed for every wave and every wave is past PV(t-1)
+    //                  LDS-DMA of tile t+2 into the slot of tile t-1;  request K fragments of tile t+1
+    //                  PV(t)
+    // Ring invariant at the loop top: tile t landed and barrier-synchronised, tile t+1 in flight, nothing else.
+    auto steady_rot = [&](const int it, v4i (&kf)[2][C::KSTEPS]) {
+        const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        float ksc_next[NH][2];
+        load_kscales(it + 1, ksc_next);
+        const unsigned char *ks = smem + cur * C::STAGE_BYTES;
+        const unsigned char *vs = ks + C::K_TILE_BYTES;
+        const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
+
+        v16i s[2];
+        if constexpr ((SAGE_ABL & 2) != 0) {
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) s[sb][i] = kSInit + kf[sb][i & 3][i >> 2] + qf[i & 3][i >> 2];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < C::KSTEPS; kk++)
+#pragma unroll
+                for (int sb = 0; sb < 2; sb++)
+                    s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
+        }
+
+        // V fragments: A operand of O^T = V^T P^T, two ds_read_b128 per 32-channel tile
+        v4u va[C::DT], vb[C::DT];
+        auto read_v = [&](int dt) {
+            const int drow = dt * 32 + n;
+            const unsigned char *vr = vs + drow * 64;
+            if constexpr ((SAGE_ABL & 64) != 0) {
+                va[dt] = v4u{(unsigned)s[0][dt], (unsigned)s[0][dt + 4], (unsigned)s[0][dt + 8], (unsigned)s[1][dt]};
+                vb[dt] = v4u{(unsigned)s[1][dt + 4], (unsigned)s[1][dt + 8], (unsigned)s[0][dt + 12], (unsigned)s[1][dt + 12]};
+            } else {
+                va[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
+                vb[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
+            }
+        };
+#pragma unroll
+        for (int dt = 0; dt < C::DT / 2; dt++) read_v(dt);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float cs[2];
+        cs[0] = (p.sm_scale_log2 * (qsc * ksc[0][0])) * kSUnit;
+        cs[1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[0][1])) * kSUnit : cs[0];
+        int mx0 = INT_MIN, mx1 = INT_MIN;
+        if constexpr ((SAGE_ABL & (128 | 1)) != 0) { mx0 = s[0][0]; mx1 = s[1][2]; }
+        else {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (KTHREAD && (i & 2)) mx1 = max(mx1, s[u][i]);
+                else mx0 = max(mx0, s[u][i]);
+            }
+        }
+        float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
+        if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
+        const float m_new = fmaxf(m_run, pair_max(mxc));
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        // The rescale sits here (not in front of the PV MFMAs) so that everything from the exponentials to the PV MFMAs is
+        // one basic block: the order pinned by the sched_barriers below survives (LLVM sinks code across a later branch).
+        if constexpr (!TWO_LEVEL || SAGE_DIRECT) {
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < C::DT; dt++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+            }
+        }
+
+        float rs = 0.0f;
+        int pw[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int sb = c >> 1, r0 = (c & 1) * 8;
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = r0 + j;
+                if constexpr ((SAGE_ABL & 1) != 0) e[j] = __int_as_float(s[sb][i]);
+                else if constexpr ((SAGE_ABL & 256) != 0) { e[j] = __builtin_fmaf(sfl(s[sb][i]), cs[(KTHREAD && (i & 2)) ? 1 : 0], -m_new); rs += e[j]; }
+                else { e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sfl(s[sb][i]), cs[(KTHREAD && (i & 2)) ? 1 : 0], -m_new)); rs += e[j]; }
+            }
+            int w0, w1;
+            if constexpr ((SAGE_ABL & (512 | 1)) != 0) {
+                w0 = __float_as_int(e[0]) ^ __float_as_int(e[1]) ^ __float_as_int(e[2]) ^ __float_as_int(e[3]);
+                w1 = __float_as_int(e[4]) ^ __float_as_int(e[5]) ^ __float_as_int(e[6]) ^ __float_as_int(e[7]);
+                if constexpr ((SAGE_ABL & 1) != 0) { w0 = s[sb][r0] ^ s[sb][r0 + 3]; w1 = s[sb][r0 + 4] ^ s[sb][r0 + 7]; }
+            } else {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], __float_as_int(e[0]), false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], __float_as_int(e[4]), false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
+            }
+            pw[2 * c] = w0;
+            pw[2 * c + 1] = w1;
+            if (c == 1) {                 // S sub-tile 0 is consumed: its registers take the second half of the V fragments
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = C::DT / 2; dt < C::DT; dt++) read_v(dt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        l_run = l_run * alpha + rs;
+
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
+        if constexpr ((SAGE_ABL & 8) == 0) issue_loads(std::true_type{}, it + 2, nn);
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            const int krow = sb * 32 + n;
+#pragma unroll
+            for (int kk = 0; kk < C::KSTEPS; kk++) {
+                if constexpr ((SAGE_ABL & 32) != 0) kf[sb][kk] = v4i{pw[kk], pw[kk + 4], pw[2 * sb], pw[2 * sb + 1]};
+                else kf[sb][kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const v8i bv = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+        if constexpr (!TWO_LEVEL || SAGE_DIRECT) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; dt++) {
+                const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3], (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
+                if constexpr ((SAGE_ABL & 4) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[dt][i] = __int_as_float(__float_as_int(o[dt][i]) ^ av[i] ^ bv[i]);
+                } else o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; dt++) {
+                const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3], (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
+                v16f acc;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+                for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
+            }
+        }
+        ksc[0][0] = ksc_next[0][0];
+        ksc[0][1] = ksc_next[0][1];
+        cur = nxt;
+    };
+#endif
     int it = 0;
 #if SAGE_STEADY
     if constexpr (MASK == 0 && NH == 1 && NSTAGE == 3) {
@@ -736,8 +921,227 @@ sage_attn_kernel(const AttnParams p)
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
         if (CAUSAL) n_steady = n_steady < 2 * qblk ? n_steady : 2 * qblk;
+
+#if SAGE_PIPE
+        if constexpr (PV_FP8 && SAGE_MXPV && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
+            // ---- software-pipelined steady state -------------------------------------------------------------
+            // Iteration t runs softmax(t) on the VALU and deals, between its instruction groups, the PV MFMAs of tile t-1
+            // (P and V fragments carried in registers) and the QK^T MFMAs of tile t+1 (K fragments read at the top), so a
+            // wave's matrix work is covered by its OWN VALU stream instead of depending on another wave being in the right
+            // phase.  The instruction ORDER is the design here, and hipcc re-orders builtin arithmetic freely (it clustered
+            // the MFMAs and sank the softmax below them), so every instruction of the main stream is a one-line
+            // `asm volatile`: hipcc still allocates the registers, counts its own ds_read / s_load / LDS-DMA and waits for
+            // them, but cannot move the statements.  Hazards it therefore does not pad (cdna_hip_programming.md 5.7):
+            //   * v_exp_f32 -> first VALU reader: one other instruction in between (groups of two scores are interleaved);
+            //   * freshly loaded / written VGPR -> MFMA A/B operand: every MFMA statement opens with s_nop 1;
+            //   * MFMA result -> VALU reader: PV results are read at the next iteration's top or after the drain's s_nops,
+            //     QK^T results after the 18-instruction tail + barrier; an MFMA taking the previous result whole as C needs none.
+            // O is rescaled (rarely) at the top of the next iteration, i.e. after PV(t-1) and before PV(t): the single-level
+            // order O = O*alpha + P V, which the FP32 MFMA accumulator makes equivalent to the two-level fold.
+            // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
+            // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
+#define A_SUBC(d, a)       asm volatile("v_add_f32 %0, 0xbe22f983, %1" : "=v"(d) : "v"(a))
+#define A_FMAN(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
+#define A_EXP(d, a)        asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a))
+#define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
+#define A_PKLO(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define A_PKHI(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(a), "v"(b))
+#define A_PV(acc, av, bv, e8) asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
+#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define A_FENCE()          asm volatile("" ::: "memory")
+            if (it < n_steady) {
+                v16i sA[2], sB[2];
+                {
+                    const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
+                    v4i kf0[2][C::KSTEPS];
+#pragma unroll
+                    for (int sb = 0; sb < 2; sb++) {
+                        const int krow = sb * 32 + n;
+#pragma unroll
+                        for (int kk = 0; kk < C::KSTEPS; kk++)
+                            kf0[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+#pragma unroll
+                        for (int sb = 0; sb < 2; sb++)
+                            sA[sb] = kk == 0 ? mfma_i8_first(kf0[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf0[sb][kk], qf[kk], sA[sb], 0, 0, 0);
+                }
+                v8i pA = {0, 0, 0, 0, 0, 0, 0, 0}, pB = {0, 0, 0, 0, 0, 0, 0, 0};   // P of the previous tile (none yet: zero, the first PV adds nothing)
+                v8i vf[C::DT];                                                        // V fragments of the previous tile
+#pragma unroll
+                for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
+                const int e8m0 = 0x7f7f7f7f;     // unit block scales
+                float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
+                auto rescale = [&]() {
+                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
+#pragma unroll
+                        for (int dt = 0; dt < C::DT; dt++)
+#pragma unroll
+                            for (int i = 0; i < 16; i++) o[dt][i] *= alpha_p;
+                    }
+                };
+                // one tile: sc = scores of tile `it` (complete), sn <- scores of tile it+1, pp = P of tile it-1, pc <- P of tile it
+                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {
+                    rescale();
+                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                    const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
+                    const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue_loads(std::true_type{}, it + 2, nn);
+                    float cs[2];
+                    cs[0] = (p.sm_scale_log2 * (qsc * ksc[0][0])) * kSUnit;
+                    cs[1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[0][1])) * kSUnit : cs[0];
+
+                    // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
+                    // (nothing is in flight on lgkmcnt here, so hipcc's own wait for the V fragments in front of this MFMA is free;
+                    //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
+                    A_PV(o[0], vf[0], pp, e8m0);
+                    A_FENCE();
+                    float ksc_next[NH][2];
+                    load_kscales(it + 1, ksc_next);
+                    v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+                        kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                    A_FENCE();
+                    int mx0 = INT_MIN, mx1 = INT_MIN;
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
+                            else mx0 = max(mx0, sc[u][i]);
+                        }
+                    float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
+                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
+                    const float m_new = fmaxf(m_run, pair_max(mxc));
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
+                    A_FENCE();
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+                        kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                    A_FENCE();
+
+                    // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
+                    float rs0 = 0.0f, rs1 = 0.0f;
+                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
+                        const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
+                        const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
+                        float t0, t1;
+                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+#define SAGE_GRP(PACK)                                                                                                          \
+                        asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"                           \
+                                     "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"                                 \
+                                     "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
+                                     "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t" PACK                                      \
+                                     : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "+v"(pc[h >> 1])                               \
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new))
+                        if ((h & 1) == 0) SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3");
+                        else SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
+#undef SAGE_GRP
+                    };
+                    auto qk_next = [&](int sb, int kk) {
+                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
+                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
+                    };
+                    auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
+                        const int drow = dt * 32 + n;
+                        const unsigned char *vr = vs + drow * 64;
+                        const v4u a = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
+                        const v4u b = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
+                        vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+                    };
+                    if constexpr (C::DT == 4) {
+                        A_PV(o[2], vf[2], pp, e8m0); grp(0); grp(1);
+                        A_PV(o[3], vf[3], pp, e8m0); grp(2); grp(3);
+                        qk_next(0, 0); grp(4);
+                        qk_next(0, 1); grp(5); grp(6);
+                        qk_next(0, 2); grp(7);
+                        qk_next(0, 3); grp(8);
+                        A_FENCE(); read_v(0); read_v(1); A_FENCE();
+                        grp(9);
+                        qk_next(1, 0); grp(10);
+                        qk_next(1, 1); grp(11); grp(12);
+                        qk_next(1, 2); grp(13);
+                        qk_next(1, 3);
+                        A_FENCE(); read_v(2); read_v(3); A_FENCE();
+                        grp(14); grp(15);
+                    } else {                         // D = 64: two PV MFMAs (dealt above), four QK^T MFMAs
+                        grp(0); grp(1); grp(2); grp(3);
+                        qk_next(0, 0); grp(4); grp(5); grp(6);
+                        qk_next(0, 1); grp(7); grp(8); grp(9);
+                        A_FENCE(); read_v(0); A_FENCE();
+                        qk_next(1, 0); grp(10); grp(11); grp(12);
+                        qk_next(1, 1);
+                        A_FENCE(); read_v(1); A_FENCE();
+                        grp(13); grp(14); grp(15);
+                    }
+                    l_run = l_run * alpha + (rs0 + rs1);
+                    ksc[0][0] = ksc_next[0][0];
+                    ksc[0][1] = ksc_next[0][1];
+                    cur = nxt;
+                    alpha_p = alpha;
+                    it++;
+                };
+                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
+                    body(sA, sB, pA, pB);
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                    sA[0] = sB[0]; sA[1] = sB[1]; pA = pB;
+                }
 #pragma nounroll
-        for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
+                while (it < n_steady) {
+                    body(sA, sB, pA, pB);
+                    body(sB, sA, pB, pA);
+                }
+                // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
+                // iteration issues the LDS-DMA of tile it+2 into that slot
+                rescale();
+#pragma unroll
+                for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA, e8m0);
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#undef A_SUBC
+#undef A_FMAN
+#undef A_EXP
+#undef A_ACC
+#undef A_PKLO
+#undef A_PKHI
+#undef A_PV
+#undef A_QK0
+#undef A_QK
+#undef A_FENCE
+        } else
+#endif
+#if SAGE_ROT
+        if constexpr (PV_FP8 && SAGE_MXPV) {
+            if (it < n_steady) {
+                v4i kf[2][C::KSTEPS];
+                const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
+#pragma unroll
+                for (int sb = 0; sb < 2; sb++) {
+                    const int krow = sb * 32 + n;
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+                        kf[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+                }
+#pragma nounroll
+                for (; it < n_steady; it++) steady_rot(it, kf);
+                // back to the general discipline (DMA of tile it+2 at the top of iteration it): every wave must be past PV(it-1)
+                __builtin_amdgcn_s_barrier();
+            }
+        } else
+#endif
+        {
+#pragma nounroll
+            for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
+        }
     }
 #endif
 #pragma nounroll

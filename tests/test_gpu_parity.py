@@ -552,14 +552,15 @@ def test_config4_varlen_gqa():
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json full sizes vs the ORACLE
 def _assert_vs_oracle(tag, got, ref_bits, dt, tol_rel=2e-3):
-    """max|o_hip - o_oracle| <= 2e-3 * max|o| + one output ulp at max|o| (the bar of the small-shape kernel tests)."""
+    """max|o_hip - o_oracle| <= 2e-3 * max|o| + one output ulp at max|o| (the bar of the small-shape kernel tests).
+    One ulp of a bf16 (fp16) number x is at most 2^-7 |x| (2^-10 |x|): the bound used here."""
     ref = util.f32(ref_bits, dt)
     assert np.isfinite(got).all()
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
     rms = float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
     REPORT[f"full_vs_oracle/{tag}"] = dict(max_abs=err, max_o=scale, rel_rms=rms, elements=int(ref.size))
-    assert err <= tol_rel * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale, f"{tag}: max|diff| {err:.3e} vs max|o| {scale:.3e}"
+    assert err <= tol_rel * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale, f"{tag}: max|diff| {err:.3e} vs max|o| {scale:.3e}"
 
 
 def test_config2_full_vs_oracle(oracle_mod):
