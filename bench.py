@@ -16,9 +16,16 @@ throughput.  The same run also times the whole `sageattn()` call (K mean + Q/K I
 under "accuracy".
 
 Multi-GPU (driver launches one rank per GPU with torch.distributed.run): the path shards by
-(batch, kv-head) units with no data-path collective (sageattention_amd/shard.py); every rank
-runs the per-GPU workload on its own units (weak scaling), the only communication is the
-barrier and the MAX-reduce of the elapsed time.
+(batch, kv-head) units with no data-path collective.  Every rank builds the GLOBAL problem (batch
+B*world, same device seed on every rank) and takes its slice with sageattention_amd.shard.shard_bh --
+the shard code is the code that runs -- so each rank holds B*H units (weak scaling); the only
+communication is the barrier and the MAX-reduce of the elapsed time.
+
+`--replay` (config c5, BASELINE.json configs[4]): the reference's drop-in usage replayed without the
+model weights -- `F.scaled_dot_product_attention = sageattn` (example/cogvideox_infer.py:34-35), then
+`--replay-layers` x `--replay-steps` (42 x 50 for CogVideoX1.5-5B) calls of F.scaled_dot_product_attention
+on the model's attention shape; with N ranks the (batch, head) units of the one global call are split
+across ranks (strong scaling, as example/run_parallel.sh splits one video over 8 GPUs).
 """
 from __future__ import annotations
 
@@ -74,15 +81,29 @@ def flops(cfg) -> float:
     return f / 2 if cfg["causal"] else f
 
 
-def make_inputs(cfg, device, seed):
-    g = torch.Generator(device="cpu").manual_seed(seed)
+def make_inputs(cfg, device, seed, batch_mult=1):
+    """randn q, k, v of the (global) problem, generated on the device: the same seed gives every rank the same
+    global tensors, which is what lets each rank take its shard of ONE problem without any communication."""
+    g = torch.Generator(device=device).manual_seed(seed)
     dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
-    shape_q = (cfg["B"], cfg["H"], cfg["N"], cfg["D"])
-    shape_k = (cfg["B"], cfg["Hkv"], cfg["N"], cfg["D"])
-    q = torch.randn(shape_q, generator=g).to(dt).to(device)
-    k = torch.randn(shape_k, generator=g).to(dt).to(device)
-    v = torch.randn(shape_k, generator=g).to(dt).to(device)
+    B = cfg["B"] * batch_mult
+    shape_q = (B, cfg["H"], cfg["N"], cfg["D"])
+    shape_k = (B, cfg["Hkv"], cfg["N"], cfg["D"])
+    q = torch.randn(shape_q, generator=g, device=device, dtype=torch.float32).to(dt)
+    k = torch.randn(shape_k, generator=g, device=device, dtype=torch.float32).to(dt)
+    v = torch.randn(shape_k, generator=g, device=device, dtype=torch.float32).to(dt)
     return q, k, v
+
+
+def rank_inputs(cfg, device, seed, rank, world, weak=True):
+    """This rank's (batch, kv-head) units of the global problem (sageattention_amd/shard.py), as [1, units*g, N, D] /
+    [1, units, N, D] tensors.  weak: the global batch is B*world (B*Hkv units per rank); strong: the global batch is B."""
+    from sageattention_amd import shard
+    q, k, v = make_inputs(cfg, device, seed, world if weak else 1)
+    qs, ks, vs, (lo, hi) = shard.shard_bh(q, k, v, rank, world)
+    qs, ks, vs = qs.contiguous(), ks.contiguous(), vs.contiguous()
+    del q, k, v
+    return qs, ks, vs, (lo, hi)
 
 
 def prequantize(cfg, q, k, v):
@@ -217,6 +238,57 @@ def run_c4(args, device):
                       "detail": out, "data": "synthetic"}))
 
 
+def run_replay(args, cfg, device, rank, world, dist_on):
+    """BASELINE.json configs[4] / SURVEY 8d C5: the drop-in replay.  F.scaled_dot_product_attention is replaced by
+    sageattn exactly as the reference's example does, then the model's attention calls are replayed: layers x steps
+    calls on the model's shape.  One global problem (batch B), its (batch, head) units split over the ranks."""
+    import torch.nn.functional as F
+    import torch.distributed as dist
+    import sageattention_amd as sa
+    q, k, v, (lo, hi) = rank_inputs(cfg, device, 4321, rank, world, weak=False)
+    orig = F.scaled_dot_product_attention
+    F.scaled_dot_product_attention = sa.sageattn                     # example/cogvideox_infer.py:34-35
+    try:
+        calls = args.replay_layers * args.replay_steps
+        for _ in range(5):
+            F.scaled_dot_product_attention(q, k, v, is_causal=cfg["causal"])
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_step = []
+        for _ in range(args.replay_steps):
+            ts = time.perf_counter()
+            for _ in range(args.replay_layers):
+                o = F.scaled_dot_product_attention(q, k, v, is_causal=cfg["causal"])
+            torch.cuda.synchronize()
+            per_step.append(time.perf_counter() - ts)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        F.scaled_dot_product_attention = orig
+    stats = torch.tensor([wall], dtype=torch.float64, device=device)
+    if dist_on:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    wall = stats.item()
+    fl = flops(cfg)                                                   # one global call
+    if rank == 0:
+        print(json.dumps({
+            "metric": "drop-in replay: F.scaled_dot_product_attention = sageattn, whole-call TFLOPS", "unit": "TFLOP/s",
+            "value": round(fl * calls / wall / 1e12, 2), "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+            "calls": calls, "layers": args.replay_layers, "denoise_steps": args.replay_steps,
+            "total_seconds": round(wall, 3), "ms_per_call": round(wall / calls * 1e3, 4),
+            "ms_per_denoise_step_attention": round(sum(per_step) / len(per_step) * 1e3, 3),
+            "config": {"workload": cfg["workload"], "global_batch": cfg["B"], "heads": cfg["H"], "seq_len": cfg["N"],
+                       "head_dim": cfg["D"], "units_this_rank": hi - lo,
+                       "parallelism": f"(batch, head) units of one call split over {world} rank(s), no collective"},
+            "dtype": "int8 QK^T + fp8(e4m3) PV, fp32 accumulate", "data": "synthetic (randn)",
+            "o_shape_rank0": list(o.shape)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +299,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--sweep", action="store_true", help="also print hd128 causal N=1k..32k kernel-only TFLOPS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replay", action="store_true", help="drop-in replay of the model's attention calls (use with --config c5)")
+    ap.add_argument("--replay-layers", type=int, default=42)
+    ap.add_argument("--replay-steps", type=int, default=50)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -257,8 +332,15 @@ def main():
         run_c4(args, device)
         return
     cfg = CONFIGS[args.config]
-    # weak scaling: every rank owns B*H (batch, kv-head) units of the global batch (B*world)
-    q, k, v = make_inputs(cfg, device, seed=1234 + rank)
+    if args.replay:
+        run_replay(args, cfg, device, rank, world, dist_on)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # weak scaling: the global batch is B*world; every rank takes its B*Hkv (batch, kv-head) units with shard_bh
+    q, k, v, _units = rank_inputs(cfg, device, 1234, rank, world, weak=True)
+    cfg = dict(cfg, B=1, H=q.shape[1], Hkv=k.shape[1], B_global=cfg["B"])          # batch folded into heads by shard_bh
     sm_scale = cfg["D"] ** -0.5
     ops = prequantize(cfg, q, k, v)
     torch.cuda.synchronize()
@@ -288,8 +370,8 @@ def main():
         "vs_baseline_note": "per-GPU kernel-only TFLOPS / 795 (SageAttn2-8b, H100, hd128 causal N=8k; BASELINE.md section 1)",
         "dtype": "int8 QK^T + " + ("fp8(e4m3) PV" if cfg["pv"] == "fp8" else "fp16 PV") + ", fp32 accumulate",
         "data": "synthetic (randn, quantised by the product's own pre-pass kernels)",
-        "config": {"workload": cfg["workload"], "global_batch": cfg["B"] * world, "heads": cfg["H"], "seq_len": cfg["N"],
-                   "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world}, no collective"},
+        "config": {"workload": cfg["workload"], "global_batch": cfg["B_global"] * world, "heads": CONFIGS[args.config]["H"], "seq_len": cfg["N"],
+                   "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world} (shard.shard_bh of the global batch), no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get(args.config),
                      "traffic_note": "HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), algorithmic 335.5e6" if args.config in PMC_TRAFFIC_BYTES else None,
@@ -309,10 +391,10 @@ def main():
         if args.sweep:
             # the config's batch (BASELINE.json: 2) and the reference bench scripts' default batch (4,
             # bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7) -- 256 CUs need the larger grid at short sequences
-            for key, bsz in (("sweep_kernel_only_tflops", cfg["B"]), ("sweep_kernel_only_tflops_batch4", 4)):
+            for key, bsz in (("sweep_kernel_only_tflops", cfg["B_global"]), ("sweep_kernel_only_tflops_batch4", 4)):
                 sweep = {}
                 for n in (1024, 2048, 4096, 8192, 16384, 32768):
-                    c = dict(cfg, N=n, B=bsz)
+                    c = dict(CONFIGS[args.config], N=n, B=bsz)
                     qq, kk, vv = make_inputs(c, device, 99)
                     oo = prequantize(c, qq, kk, vv)
                     _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 20, 5, False, min(args.ramp_seconds, 0.2))

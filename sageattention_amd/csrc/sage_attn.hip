@@ -920,7 +920,11 @@ sage_attn_kernel(const AttnParams p)
         // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
+#ifdef SAGE_HACK_NODIAG      // timing experiment only (wrong results): diagonal tiles run unmasked through the steady loop
+        { int ns2 = Lk / KT - 2; n_steady = ns2 < n_iters ? ns2 : n_iters; }
+#else
         if (CAUSAL) n_steady = n_steady < 2 * qblk ? n_steady : 2 * qblk;
+#endif
 
 #if SAGE_PIPE
         if constexpr (PV_FP8 && SAGE_MXPV && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
@@ -973,6 +977,7 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
                 const int e8m0 = 0x7f7f7f7f;     // unit block scales
+                const float sm26 = p.sm_scale_log2 * kSUnit;
                 float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
                 auto rescale = [&]() {
                     if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
@@ -990,25 +995,29 @@ sage_attn_kernel(const AttnParams p)
                     const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    issue_loads(std::true_type{}, it + 2, nn);
-                    float cs[2];
-                    cs[0] = (p.sm_scale_log2 * (qsc * ksc[0][0])) * kSUnit;
-                    cs[1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[0][1])) * kSUnit : cs[0];
+                    if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
+                    if constexpr ((SAGE_ABL & 8) == 0) issue_loads(std::true_type{}, it + 2, nn);
+                    float cs[2];                 // (sm * (q_scale * k_scale)) * 2^26 == (sm * 2^26) * (q_scale * k_scale): exact power-of-two scaling
+                    cs[0] = sm26 * (qsc * ksc[0][0]);
+                    cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
 
                     // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
                     // (nothing is in flight on lgkmcnt here, so hipcc's own wait for the V fragments in front of this MFMA is free;
                     //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
-                    A_PV(o[0], vf[0], pp, e8m0);
+                    if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[0], vf[0], pp, e8m0);
                     A_FENCE();
                     float ksc_next[NH][2];
                     load_kscales(it + 1, ksc_next);
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
 #pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-                        kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                    for (int kk = 0; kk < C::KSTEPS; kk++) {
+                        if constexpr ((SAGE_ABL & 32) != 0) kfa[kk] = qf[kk];
+                        else kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                    }
                     A_FENCE();
                     int mx0 = INT_MIN, mx1 = INT_MIN;
+                    if constexpr ((SAGE_ABL & 128) != 0) { mx0 = sc[0][0]; mx1 = sc[0][2]; }
+                    else {
 #pragma unroll
                     for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -1016,16 +1025,19 @@ sage_attn_kernel(const AttnParams p)
                             if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
                             else mx0 = max(mx0, sc[u][i]);
                         }
+                    }
                     float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
                     if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
                     const float m_new = fmaxf(m_run, pair_max(mxc));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
-                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
+                    if constexpr (C::DT > 1 && (SAGE_ABL & 4) == 0) A_PV(o[1], vf[1], pp, e8m0);
                     A_FENCE();
 #pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-                        kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                    for (int kk = 0; kk < C::KSTEPS; kk++) {
+                        if constexpr ((SAGE_ABL & 32) != 0) kfb[kk] = qf[kk];
+                        else kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                    }
                     A_FENCE();
 
                     // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
@@ -1033,6 +1045,7 @@ sage_attn_kernel(const AttnParams p)
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
+                        if constexpr ((SAGE_ABL & 1) != 0) return;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
 #define SAGE_GRP(PACK)                                                                                                          \
@@ -1047,10 +1060,12 @@ sage_attn_kernel(const AttnParams p)
 #undef SAGE_GRP
                     };
                     auto qk_next = [&](int sb, int kk) {
+                        if constexpr ((SAGE_ABL & 2) != 0) return;
                         if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
                         else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
                     };
                     auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
+                        if constexpr ((SAGE_ABL & 64) != 0) return;
                         const int drow = dt * 32 + n;
                         const unsigned char *vr = vs + drow * 64;
                         const v4u a = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
@@ -1058,8 +1073,10 @@ sage_attn_kernel(const AttnParams p)
                         vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
                     };
                     if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp, e8m0); grp(0); grp(1);
-                        A_PV(o[3], vf[3], pp, e8m0); grp(2); grp(3);
+                        if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[2], vf[2], pp, e8m0);
+                        grp(0); grp(1);
+                        if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[3], vf[3], pp, e8m0);
+                        grp(2); grp(3);
                         qk_next(0, 0); grp(4);
                         qk_next(0, 1); grp(5); grp(6);
                         qk_next(0, 2); grp(7);
