@@ -50,6 +50,7 @@ extern "C" {
 #define SAGE_GRAN_PER_BLOCK 1
 #define SAGE_GRAN_PER_WARP 2
 #define SAGE_GRAN_PER_THREAD 3
+#define SAGE_GRAN_KBLK128 0x100      /* OR-ed into qk_quant_gran: k scale groups span 128 keys (sm90 kernels, core.py:964-970) */
 
 /* rounding / epsilon convention of the INT8 quantiser */
 #define SAGE_QSTYLE_TRITON 0         /* quant_per_block.py:39-47: x/scale, round half away, no eps */

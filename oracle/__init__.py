@@ -181,7 +181,7 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
                    qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32,
-                   smooth_v=False, vm=None, mask_bool=None, mask_add=None):
+                   smooth_v=False, vm=None, mask_bool=None, mask_add=None, blkk=64):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -189,6 +189,8 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
     pv "f8": sageattn_qk_int8_pv_fp8_cuda (core.py:636-826) with fp32+fp32 two-level
         accumulation; qk_quant_gran per_warp | per_thread (| per_block, our extension).
     pv "f16": sageattn_qk_int8_pv_fp16_cuda pv_accum_dtype="fp32" (core.py:451-633).
+    warpq / blkk: scale-group sizes of the CUDA-named APIs -- WARPQ 32, or 16 for head_dim 128 with
+        "fp16+fp32" (core.py:602-604); the sm90 entry point uses WARPQ 16 and BLKK = WARPK = 128 (core.py:964-970).
     Returns (o bits [B,Hq,Lq,D0], lse or None, aux dict of intermediates).
     """
     D0 = q.shape[-1]
@@ -213,13 +215,13 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
         c = 1.0
     elif qk_quant_gran == "per_warp":
         gq, nq = group_index(Lq, "per_warp", "q", 128, warpq)     # WARPQ 32, or 16 (core.py:602)
-        gk, nk = group_index(Lk, "per_warp", "k", 64, 64)
+        gk, nk = group_index(Lk, "per_warp", "k", blkk, blkk)
         q8, qs = quant_int8(q, dtype, gq, nq, style=STYLE_CUDA)
         k8, ks = quant_int8(k, dtype, gk, nk, style=STYLE_CUDA, mean=km)
         c = float(np.float32(sm_scale) * np.float32(LOG2E))
     elif qk_quant_gran == "per_thread":
-        gq, nq = group_index(Lq, "per_thread", "q", 128, 32)
-        gk, nk = group_index(Lk, "per_thread", "k", 64, 64)
+        gq, nq = group_index(Lq, "per_thread", "q", 128, warpq)
+        gk, nk = group_index(Lk, "per_thread", "k", blkk, blkk)
         q8, qs = quant_int8(q, dtype, gq, nq, style=STYLE_TRITON_THREAD)
         k8, ks = quant_int8(k, dtype, gk, nk, style=STYLE_TRITON_THREAD, mean=km)
         c = float(np.float32(sm_scale) * np.float32(LOG2E))

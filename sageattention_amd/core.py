@@ -82,8 +82,8 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     # Under torch.compile the registered custom ops are traced; in eager mode their implementations are
     # called directly (same code, minus ~15 us of dispatcher overhead per call).
     compiling = torch.compiler.is_compiling()
-    f8 = ops.qk_int8_sv_f8_attn if compiling else getattr(ops.qk_int8_sv_f8_attn, "_init_fn", ops.qk_int8_sv_f8_attn)
-    f16 = ops.qk_int8_sv_f16_attn if compiling else getattr(ops.qk_int8_sv_f16_attn, "_init_fn", ops.qk_int8_sv_f16_attn)
+    f8 = ops.qk_int8_sv_f8_attn if compiling else ops.qk_int8_sv_f8_attn_impl
+    f16 = ops.qk_int8_sv_f16_attn if compiling else ops.qk_int8_sv_f16_attn_impl
     if fp8:
         lse = f8(q_int8, k_int8, v_image, o, q_scale, k_scale, v_scale, v_mean, layout, int(is_causal),
                  gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
@@ -153,6 +153,9 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
     (the reference's sm90 choice, ``pv_accum_dtype="fp32+fp32"``).  Extra SDPA-style kwargs
     (``attn_mask=``, ``dropout_p=``, ``scale=`` ...) are accepted and ignored exactly as the
     reference ignores them."""
+    if torch.compiler.is_compiling():      # the device query is not traceable; the opaque op checks the device when it runs
+        return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
+                                            return_lse=return_lse, pv_accum_dtype="fp32+fp32")
     arch = get_gcn_arch(q.device) if q.is_cuda else "cpu"
     if arch.startswith(_SUPPORTED_ARCH_PREFIX):
         return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
@@ -228,6 +231,14 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     return o[..., :head_dim_og]
 
 
+def _compiled_call(api, q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse):
+    """torch.compile route of the dense CUDA-named entry points: one opaque custom op around the eager pipeline (ops.py)."""
+    o, lse = ops.sageattn_call(q, k, v, api, tensor_layout, bool(is_causal), qk_quant_gran,
+                               None if sm_scale is None else float(sm_scale), pv_accum_dtype, bool(smooth_k), bool(smooth_v),
+                               bool(return_lse))
+    return (o, lse) if return_lse else o
+
+
 def _sm_log2(sm_scale: float) -> float:
     """sm_scale * log2(e) as the CUDA kernels form it: the Python double becomes a float kernel argument and is
     multiplied by the fp32 constant in fp32 (`sm_scale *= math::log2e`, qk_int_sv_f8_cuda_sm89.cuh:90, math.cuh:32).
@@ -235,14 +246,19 @@ def _sm_log2(sm_scale: float) -> float:
     return ctypes.c_float(ctypes.c_float(sm_scale).value * ctypes.c_float(1.44269504088896340736).value).value
 
 
-def _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale):
-    """Returns (q_int8, q_scale, k_int8, k_scale, gran code, q_warp, sm_scale_log2)."""
+def _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale, blkk=64):
+    """Returns (q_int8, q_scale, k_int8, k_scale, gran code, q_warp, sm_scale_log2).  ``warpq`` (32 / 16) and ``blkk`` (64 /
+    128) are the reference kernels' scale-group sizes (core.py:602-604, 964-970); the row -> group maps do not depend on the
+    q block size, so BLKQ = 128 here also reproduces the sm90 kernels' BLKQ = 64 groups."""
+    kflag = _cabi.GRAN_KBLK128 if blkk == 128 else 0
     if qk_quant_gran == "per_warp":
-        return (*per_warp_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=64),
-                _cabi.GRAN_PER_WARP, warpq, _sm_log2(sm_scale))
+        return (*per_warp_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=blkk),
+                _cabi.GRAN_PER_WARP | kflag, warpq, _sm_log2(sm_scale))
     if qk_quant_gran == "per_thread":
-        return (*per_thread_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64),
-                _cabi.GRAN_PER_THREAD, 32, _sm_log2(sm_scale))
+        return (*per_thread_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=blkk, WARPK=blkk),
+                _cabi.GRAN_PER_THREAD | kflag, warpq, _sm_log2(sm_scale))
+    if blkk != 64:
+        raise ValueError("per_block scales are defined for 64-key groups only")
     # "per_block": gfx950 extension (the Triton path's granularity with the CUDA rounding)
     return (*per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout, quantization_backend="cuda"),
             _cabi.GRAN_PER_BLOCK, 128, 1.0)
@@ -255,6 +271,8 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     """INT8 QK^T + FP16 PV (reference core.py:451-633).  ``pv_accum_dtype`` "fp32" accumulates
     straight into FP32; "fp16+fp32" keeps the reference's per-tile buffer structure (the tile
     buffer is FP32 here: CDNA4 MFMA has no FP16 accumulator); "fp16" maps to "fp32"."""
+    if torch.compiler.is_compiling():
+        return _compiled_call("fp16", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse)
     dtype = q.dtype
     _check_inputs(q, k, v)
     assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
@@ -269,7 +287,7 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     if pv_accum_dtype in ["fp32", "fp16+fp32"] and smooth_v:
         warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")   # core.py:608-610
         smooth_v = False
-    warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32" and qk_quant_gran == "per_warp") else 32
+    warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32") else 32              # core.py:602-604
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale)
     vm = None
     if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
@@ -290,6 +308,8 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     run the two-level kernel with an FP32 tile buffer (gfx950's FP8 MFMA only writes FP32, so V
     keeps the full ``scale_max=448``; the reference's 2.25 is an FP16-accumulator artefact,
     core.py:805-807); "fp32" accumulates every tile straight into the output registers."""
+    if torch.compiler.is_compiling():
+        return _compiled_call("fp8", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse)
     dtype = q.dtype
     _check_inputs(q, k, v)
     assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
@@ -304,8 +324,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     if pv_accum_dtype in ("fp32+fp32", "fp32+fp16") and smooth_v:
         warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")   # core.py:797-803
         smooth_v = False
-    fuse_q = (qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
-              and not torch.compiler.is_compiling())
+    fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
     if fuse_q:
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM)
         km_s = _squeeze_km(km, tensor_layout)
@@ -325,9 +344,26 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_ca
                                       qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
                                       pv_accum_dtype: str = "fp32+fp32", smooth_k: bool = True, return_lse: bool = False,
                                       **kwargs: Any):
-    """Kept for drop-in (reference core.py:829-996): same gfx950 kernel, two-level accumulation."""
+    """Kept for drop-in (reference core.py:829-996).  Same gfx950 kernel and two-level accumulation as
+    ``sageattn_qk_int8_pv_fp8_cuda``, with the sm90 kernels' scale groups: q per 16 rows (per-warp) or the 8 per-thread
+    slots of every 16 rows, k per 128 keys (core.py:964-970: BLKQ=64, WARPQ=16, BLKK=128, WARPK=128)."""
     if pv_accum_dtype == "fp32":
         raise NotImplementedError("Please use pv_accum_dtype='fp32+fp32' for sm90.")   # core.py:985-986
-    return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, qk_quant_gran=qk_quant_gran,
-                                        sm_scale=sm_scale, pv_accum_dtype=pv_accum_dtype, smooth_k=smooth_k,
-                                        return_lse=return_lse)
+    if pv_accum_dtype != "fp32+fp32":
+        raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
+    if torch.compiler.is_compiling():
+        return _compiled_call("sm90", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, False, return_lse)
+    dtype = q.dtype
+    _check_inputs(q, k, v)
+    assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
+    torch.cuda.set_device(v.device)
+    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    if sm_scale is None:
+        sm_scale = head_dim_og ** -0.5
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 16, sm_scale, blkk=128)
+    v_image, v_scale, _ = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=False)
+    o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
+                         gran, q_warp, sm_log2, True, return_lse)
+    return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)

@@ -259,6 +259,7 @@ sage_attn_kernel(const AttnParams p)
         if (p.q_gran == QG_PER_BLOCK) slot = 0;
         else if (p.q_gran == QG_PER_WARP32) slot = rin >> 5;
         else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
+        else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
         else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
         qsc = qs_ptr[slot * qs_stride];
     } else {
@@ -419,7 +420,7 @@ sage_attn_kernel(const AttnParams p)
         for (int hh = 0; hh < NH; hh++) {
             int tk = it * NH + hh;
             tk = tk < ntk_all ? tk : ntk_all - 1;
-            const long tb = (long)tk * ks_tstride;
+            const long tb = (long)(tk >> p.ks_shift) * ks_tstride;
             if (KTHREAD) {      // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83); lane half g uses 2g, 2g+1
                 const float s0 = ks_c[tb], s1 = ks_c[tb + 1], s2 = ks_c[tb + 2], s3 = ks_c[tb + 3];
                 dst[hh][0] = g ? s2 : s0;

@@ -47,7 +47,10 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     SAGE_REQUIRE(varlen || Lk > 0, "kv_len must be positive");
     SAGE_REQUIRE(Hq % Hkv == 0, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
     SAGE_REQUIRE(out_dtype == SAGE_DTYPE_F16 || out_dtype == SAGE_DTYPE_BF16, "bad out_dtype %d", out_dtype);
+    const bool k128 = (gran & SAGE_GRAN_KBLK128) != 0;       // k scale groups of 128 keys (sm90 configuration)
+    gran &= ~SAGE_GRAN_KBLK128;
     SAGE_REQUIRE(gran >= SAGE_GRAN_PER_BLOCK && gran <= SAGE_GRAN_PER_THREAD, "bad qk_quant_gran %d", gran);
+    SAGE_REQUIRE(!k128 || (!varlen && mask == nullptr), "128-key k scale groups: dense, unmasked attention only");
     SAGE_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v_image) && aligned16(o), "q/k/v/o must be 16-byte aligned");
     SAGE_REQUIRE(q_sl % 16 == 0 && k_sl % 16 == 0 && q_sh % 16 == 0 && k_sh % 16 == 0 && q_sb % 16 == 0 && k_sb % 16 == 0,
                  "int8 q/k strides must be multiples of 16");
@@ -72,12 +75,14 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
         p.q_gran = q_warp == 32 ? sage::QG_PER_WARP32 : sage::QG_PER_WARP16;
         p.qs_per_blk = sage::BLKQ / q_warp;
     } else {
-        SAGE_REQUIRE(q_warp == 32, "per_thread is defined for WARPQ=32 only (got %d)", q_warp);
-        p.q_gran = sage::QG_PER_THREAD; p.qs_per_blk = 32; kthread = true;
+        SAGE_REQUIRE(q_warp == 32 || q_warp == 16, "per_thread q_warp must be 32 or 16 (got %d)", q_warp);
+        p.q_gran = q_warp == 32 ? sage::QG_PER_THREAD : sage::QG_PER_THREAD16;
+        p.qs_per_blk = (sage::BLKQ / q_warp) * 8; kthread = true;
     }
     SAGE_REQUIRE(!varlen || gran == SAGE_GRAN_PER_BLOCK, "varlen supports per_block scales only");
     p.nqs = p.nqblk * p.qs_per_blk;
-    p.nks = ((Lk + sage::BLKK - 1) / sage::BLKK) * (kthread ? 4 : 1);
+    p.ks_shift = k128 ? 1 : 0;
+    p.nks = ((Lk + (sage::BLKK << p.ks_shift) - 1) / (sage::BLKK << p.ks_shift)) * (kthread ? 4 : 1);
     p.out_dtype = out_dtype;
     p.lse_sh = 0;
     p.sm_scale_log2 = sm_scale_log2;

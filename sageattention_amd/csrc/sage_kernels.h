@@ -6,7 +6,7 @@
 namespace sage {
 
 // query-scale granularity as seen by the attention kernel (slots per 128-row block)
-enum : int { QG_PER_BLOCK = 1, QG_PER_WARP32 = 2, QG_PER_THREAD = 3, QG_PER_WARP16 = 4 };
+enum : int { QG_PER_BLOCK = 1, QG_PER_WARP32 = 2, QG_PER_THREAD = 3, QG_PER_WARP16 = 4, QG_PER_THREAD16 = 5 };
 
 struct AttnParams {
     const void *q;            // int8 (or fp16 / bf16 for the fused-Q kernels), strides below (elements)
@@ -34,6 +34,7 @@ struct AttnParams {
     int nqs, nks;             // scale slots per (b,h) for q / k (dense)
     int qs_per_blk;           // q scale slots per 128-row block
     int q_gran;               // QG_*
+    int ks_shift;             // k scale groups span 64 << ks_shift keys (1: the sm90 kernels' 128-key groups, core.py:964-970)
     int out_dtype;            // DT_F16 / DT_BF16
     long lse_sh;              // varlen lse head stride (unused for dense)
     float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain

@@ -30,7 +30,7 @@ quant_int8_kernel(const QuantParams p)
 {
     constexpr int CPR = D / 16;                 // 16-element chunks per row
     constexpr int NCH = BLK * CPR / 256;        // chunks per thread
-    __shared__ unsigned gmax[32];
+    __shared__ unsigned gmax[64];          // up to (128 / 16) * 8 per-thread groups
 
     const int tid = threadIdx.x;
     const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -56,7 +56,7 @@ quant_int8_kernel(const QuantParams p)
         sc_out = p.scale + ((long)b * p.H + h) * p.nscale + (long)blk * ngroups;
     }
     const unsigned init_bits = (p.style == QS_CUDA) ? __float_as_uint(1e-7f) : 0u;   // fused.cu:147
-    if (tid < 32) gmax[tid] = init_bits;
+    if (tid < 64) gmax[tid] = init_bits;
     __syncthreads();
 
     const uint16_t *x = reinterpret_cast<const uint16_t *>(p.x) + xoff;

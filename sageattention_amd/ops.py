@@ -34,8 +34,7 @@ def _lse_alloc(query: torch.Tensor, tensor_layout: int, return_lse: int) -> torc
     return torch.empty((0,), dtype=torch.float32, device=query.device)      # reference: torch::empty({0})
 
 
-@torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f8_attn", mutates_args=("output",), device_types="cuda")
-def qk_int8_sv_f8_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
+def qk_int8_sv_f8_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
                        query_scale: torch.Tensor, key_scale: torch.Tensor, value_scale: torch.Tensor,
                        value_mean: Optional[torch.Tensor], tensor_layout: int, is_causal: int, qk_quant_gran: int,
                        q_warp: int, sm_scale_log2: float, pv_accum: int, return_lse: int) -> torch.Tensor:
@@ -54,14 +53,18 @@ def qk_int8_sv_f8_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Te
     return lse
 
 
+# the plain function stays importable (eager callers use it directly, skipping the dispatcher); the registered op wraps it
+qk_int8_sv_f8_attn = torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f8_attn", qk_int8_sv_f8_attn_impl,
+                                             mutates_args=("output",), device_types="cuda")
+
+
 @qk_int8_sv_f8_attn.register_fake
 def _(query, key, v_image, output, query_scale, key_scale, value_scale, value_mean, tensor_layout, is_causal,
       qk_quant_gran, q_warp, sm_scale_log2, pv_accum, return_lse):
     return _lse_alloc(query, tensor_layout, return_lse)
 
 
-@torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f16_attn", mutates_args=("output",), device_types="cuda")
-def qk_int8_sv_f16_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
+def qk_int8_sv_f16_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
                         query_scale: torch.Tensor, key_scale: torch.Tensor, value_mean: Optional[torch.Tensor],
                         tensor_layout: int, is_causal: int, qk_quant_gran: int, q_warp: int, sm_scale_log2: float,
                         pv_accum: int, return_lse: int) -> torch.Tensor:
@@ -80,7 +83,43 @@ def qk_int8_sv_f16_attn(query: torch.Tensor, key: torch.Tensor, v_image: torch.T
     return lse
 
 
+qk_int8_sv_f16_attn = torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f16_attn", qk_int8_sv_f16_attn_impl,
+                                              mutates_args=("output",), device_types="cuda")
+
+
 @qk_int8_sv_f16_attn.register_fake
 def _(query, key, v_image, output, query_scale, key_scale, value_mean, tensor_layout, is_causal, qk_quant_gran, q_warp,
       sm_scale_log2, pv_accum, return_lse):
     return _lse_alloc(query, tensor_layout, return_lse)
+
+
+# ------------------------------------------------------------------------------------------------ whole-call op
+# Under torch.compile the public entry points (core.sageattn*, dense) dispatch to ONE opaque op that runs the eager
+# pipeline -- K mean, INT8 / FP8 pre-pass kernels, fused attention -- so a compiled model has no graph break around the
+# attention call, with any backend (the pre-pass kernels go through ctypes, which dynamo cannot trace).
+def sageattn_call_impl(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, api: str, tensor_layout: str, is_causal: bool,
+                       qk_quant_gran: str, sm_scale: Optional[float], pv_accum_dtype: str, smooth_k: bool, smooth_v: bool,
+                       return_lse: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    from . import core
+    fn = {"fp8": core.sageattn_qk_int8_pv_fp8_cuda, "fp16": core.sageattn_qk_int8_pv_fp16_cuda,
+          "sm90": core.sageattn_qk_int8_pv_fp8_cuda_sm90}[api]
+    kw = dict(tensor_layout=tensor_layout, is_causal=is_causal, qk_quant_gran=qk_quant_gran, sm_scale=sm_scale,
+              pv_accum_dtype=pv_accum_dtype, smooth_k=smooth_k, return_lse=return_lse)
+    if api != "sm90":
+        kw["smooth_v"] = smooth_v
+    out = fn(q, k, v, **kw)
+    o, lse = out if return_lse else (out, torch.empty((0,), dtype=torch.float32, device=q.device))
+    return o.contiguous(), lse
+
+
+sageattn_call = torch.library.custom_op("sageattention_gfx950::sageattn_call", sageattn_call_impl, mutates_args=(),
+                                        device_types="cuda")
+
+
+@sageattn_call.register_fake
+def _(q, k, v, api, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse):
+    o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    if return_lse:
+        B, H, L = (q.shape[0], q.shape[1], q.shape[2]) if tensor_layout == "HND" else (q.shape[0], q.shape[2], q.shape[1])
+        return o, torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+    return o, torch.empty((0,), dtype=torch.float32, device=q.device)

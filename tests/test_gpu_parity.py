@@ -272,6 +272,35 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3     # q.km^T correction is rounded to fp16/bf16
 
 
+@pytest.mark.parametrize("gran", ["per_warp", "per_thread"])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 2, 4, 5)], ids=[CASES[i][0] for i in (0, 2, 4, 5)])
+def test_sm90_entry_point_scale_groups_vs_oracle(oracle_mod, case, causal, gran):
+    """sageattn_qk_int8_pv_fp8_cuda_sm90 with the sm90 kernels' scale groups (core.py:964-970): q scales per 16 rows
+    (or the 8 per-thread slots of every 16 rows), k scales per 128 keys -- against the oracle quantising with those groups."""
+    name, B, Hq, Hkv, Lq, Lk, D, dt = case
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=300 + Lq, kbias=1.5)
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    o_bits, lse_ref, aux = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
+                                                     qk_quant_gran=gran, return_lse=True, km=km, warpq=16, blkk=128)
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda_sm90(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=causal, qk_quant_gran=gran,
+                                                  pv_accum_dtype="fp32+fp32", return_lse=True)
+    torch.cuda.synchronize()
+    got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    REPORT[f"sm90_groups/{name}/{'c' if causal else 'nc'}/{gran}"] = dict(max_abs=err, max_o=scale)
+    assert np.isfinite(got).all() and err <= 2e-3 * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
+    # the INT8 operands themselves: bit-exact against the oracle's quantiser with the same groups
+    q8, qs, k8, ks = (sq.per_warp_int8(q.to(DEV), k.to(DEV), util.from_bits(km, dt, DEV), BLKQ=128, WARPQ=16, BLKK=128) if gran == "per_warp"
+                      else sq.per_thread_int8(q.to(DEV), k.to(DEV), util.from_bits(km, dt, DEV), BLKQ=128, WARPQ=16, BLKK=128, WARPK=128))
+    assert (q8.cpu().numpy() == aux["q8"]).all() and (k8.cpu().numpy() == aux["k8"]).all()
+    assert (qs.cpu().numpy() == aux["qs"]).all() and (ks.cpu().numpy() == aux["ks"]).all()
+    with pytest.raises(NotImplementedError):
+        sa.sageattn_qk_int8_pv_fp8_cuda_sm90(q.to(DEV), k.to(DEV), v.to(DEV), pv_accum_dtype="fp32")
+
+
 EDGE = [  # B, Hq, Hkv, Lq, Lk, D
     (1, 1, 1, 1, 1, 64), (1, 3, 3, 5, 3, 128), (1, 6, 3, 127, 63, 64), (3, 1, 1, 129, 65, 128),
     (1, 2, 1, 64, 64, 128), (1, 5, 5, 257, 191, 64), (2, 3, 1, 33, 1000, 128),
@@ -478,6 +507,33 @@ def test_torch_compile_traces_through_the_custom_ops():
     got = torch.compile(block, backend="aot_eager")(q, k, v)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("backend", ["aot_eager", "inductor"])
+def test_torch_compile_fullgraph_no_graph_break(backend):
+    """The whole dense call is ONE opaque op under torch.compile (ops.sageattn_call): fullgraph=True compiles -- no graph
+    break around the ctypes pre-pass -- and the compiled attention is bit-equal to the eager one (same kernels, same route)."""
+    q, k, v = (t.to(DEV) for t in rand_qkv(2, 4, 2, 300, 333, 128, 1, seed=23))
+    torch._dynamo.reset()
+
+    def attn_only(q, k, v):
+        return sa.sageattn(q, k, v, is_causal=False)
+
+    def with_lse(q, k, v):
+        o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True, pv_accum_dtype="fp32", return_lse=True)
+        return o * 2.0, lse
+
+    want = attn_only(q, k, v)
+    got = torch.compile(attn_only, backend=backend, fullgraph=True)(q, k, v)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    qs, ks, vs = q[:, :, :256], k[:, :2, :256], v[:, :2, :256]
+    o_w, lse_w = with_lse(qs, ks, vs)
+    o_g, lse_g = torch.compile(with_lse, backend=backend, fullgraph=True)(qs, ks, vs)
+    torch.cuda.synchronize()
+    assert torch.equal(lse_g, lse_w) and torch.allclose(o_g.float(), o_w.float(), rtol=1e-2, atol=1e-3)
+    from sageattention_amd import ops as ops_mod
+    torch.library.opcheck(ops_mod.sageattn_call, (q, k, v, "fp8", "HND", False, "per_thread", None, "fp32+fp32", True, False, True))
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json full sizes
