@@ -143,7 +143,7 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
         SAGE_REQUIRE(warp > 0 && blk % warp == 0 && warp % 8 == 0, "bad warp block %d for blk %d", warp, blk);
         p.gran = is_key ? sage::GR_THREAD_K : sage::GR_THREAD_Q;
         slots = (blk / warp) * (is_key ? 4 : 8);
-        SAGE_REQUIRE(slots <= 32, "too many scale groups per block (%d)", slots);
+        SAGE_REQUIRE(slots <= 64, "too many scale groups per block (%d)", slots);
     } else return fail(SAGE_EINVAL, "bad qk_quant_gran %d", gran);
     p.nscale = ((L + blk - 1) / blk) * slots;
     return check_launch(sage::launch_quant_int8(p, static_cast<hipStream_t>(stream)), "sage_quant_qk_int8 launch");
