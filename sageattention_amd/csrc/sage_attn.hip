@@ -60,6 +60,9 @@
 #ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
 #define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
 #endif
+#ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
+#define SAGE_ASMDMA 1   // M0 write per image, inst_offset for the second piece) instead of four builtins with 64-bit VGPR addresses
+#endif
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
@@ -978,6 +981,12 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
                 const int e8m0 = 0x7f7f7f7f;     // unit block scales
+#if SAGE_ASMDMA
+                static_assert(KP / 4 == VP / 4 && (KP / 4 == 1 || KP / 4 == 2), "asm LDS-DMA: one or two pieces per wave and image");
+                const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+                const unsigned voff16 = lane * 16;
+                const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;    // piece 1's source offset minus its inst_offset
+#endif
                 const float sm26 = p.sm_scale_log2 * kSUnit;
                 float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
                 auto rescale = [&]() {
@@ -997,7 +1006,33 @@ sage_attn_kernel(const AttnParams p)
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
-                    if constexpr ((SAGE_ABL & 8) == 0) issue_loads(std::true_type{}, it + 2, nn);
+                    if constexpr ((SAGE_ABL & 8) == 0) {
+#if SAGE_ASMDMA
+                        // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
+                        // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
+                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
+                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 2) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
+                        const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
+                        const unsigned ldv = lds_base + nn * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
+                        unsigned keep;
+                        if constexpr (KP / 4 == 2)
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %7, %4\n\tglobal_load_lds_dwordx4 %7, %4 offset:1024\n\t"
+                                         "s_mov_b32 m0, %0"
+                                         : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                        else
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %1, %2\n\t"
+                                         "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %6, %3\n\t"
+                                         "s_mov_b32 m0, %0"
+                                         : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+#else
+                        issue_loads(std::true_type{}, it + 2, nn);
+#endif
+                    }
                     float cs[2];                 // (sm * (q_scale * k_scale)) * 2^26 == (sm * 2^26) * (q_scale * k_scale): exact power-of-two scaling
                     cs[0] = sm26 * (qsc * ksc[0][0]);
                     cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
