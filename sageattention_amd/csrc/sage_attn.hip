@@ -254,7 +254,13 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             v4i z = {0, 0, 0, 0};
+#ifdef SAGE_HACK_NOQ         // timing experiment only: no Q loads
+            qf[ks] = v4i{lane, ks, lane * 3, 7};
+#elif defined(SAGE_HACK_QHOT) // timing experiment only: every workgroup reads the first 128 rows of the tensor (cache-hot, realistic values)
+            qf[ks] = *reinterpret_cast<const v4i *>(reinterpret_cast<const int8_t *>(p.q) + (long)(wave * 32 + n) * p.q_sl + 32 * ks + 16 * g);
+#else
             qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
+#endif
         }
         // this lane's query-row scale (per-block / per-warp / per-thread granularity)
         int slot;
@@ -264,7 +270,13 @@ sage_attn_kernel(const AttnParams p)
         else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
         else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
         else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
+#ifdef SAGE_HACK_NOQ
+        qsc = 0.01f + 1e-6f * slot;
+#elif defined(SAGE_HACK_QHOT)
+        qsc = p.q_scale[slot];
+#else
         qsc = qs_ptr[slot * qs_stride];
+#endif
     } else {
         // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
         // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
@@ -1200,6 +1212,10 @@ sage_attn_kernel(const AttnParams p)
 #pragma nounroll
     for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
+#ifdef SAGE_HACK_NOEPI       // timing experiment only: one store per wave instead of the epilogue
+    if (lane == 0) reinterpret_cast<float *>(p.o)[(o_off + (long)row0 * p.o_sl) / 2] = o[0][0] + o[1][1] + l_run + m_run;
+    return;
+#endif
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
     const float l_tot = pair_sum(l_run);
@@ -1216,21 +1232,26 @@ sage_attn_kernel(const AttnParams p)
     // vmcnt(0) each time: 128 serial L2 round trips per workgroup)
     const float *vsc = PV_FP8 ? p.v_scale + ((long)b * p.Hkv + hk) * D : nullptr;
     const float *vmn = (p.v_mean != nullptr) ? p.v_mean + ((long)b * p.Hkv + hk) * D : nullptr;
+    // every factor of the tile is requested before the first one is used: one exposed memory latency per workgroup
+    // instead of one per 32-channel tile (the slot is idle for the co-resident workgroup's sake until this one retires)
+    v4f sc4[C::DT][4], mn4[C::DT][4];
 #pragma unroll
     for (int dt = 0; dt < C::DT; dt++) {
-        v4f sc4[4], mn4[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
             const v4f one = {1.0f, 1.0f, 1.0f, 1.0f};
-            sc4[r4] = PV_FP8 ? *reinterpret_cast<const v4f *>(vsc + dt * 32 + 8 * r4 + 4 * g) : one;
+            sc4[dt][r4] = PV_FP8 ? *reinterpret_cast<const v4f *>(vsc + dt * 32 + 8 * r4 + 4 * g) : one;
         }
         if (vmn != nullptr) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) mn4[r4] = *reinterpret_cast<const v4f *>(vmn + dt * 32 + 8 * r4 + 4 * g);
+            for (int r4 = 0; r4 < 4; r4++) mn4[dt][r4] = *reinterpret_cast<const v4f *>(vmn + dt * 32 + 8 * r4 + 4 * g);
         } else {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) { const v4f z = {0.0f, 0.0f, 0.0f, 0.0f}; mn4[r4] = z; }
+            for (int r4 = 0; r4 < 4; r4++) { const v4f z = {0.0f, 0.0f, 0.0f, 0.0f}; mn4[dt][r4] = z; }
         }
+    }
+#pragma unroll
+    for (int dt = 0; dt < C::DT; dt++) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
             const int d0 = dt * 32 + 8 * r4 + 4 * g;           // 4 consecutive d: regs 4*r4 .. 4*r4+3
@@ -1238,8 +1259,8 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 x[j] = o[dt][4 * r4 + j] * inv;
-                if (PV_FP8) x[j] *= sc4[r4][j];
-                x[j] += mn4[r4][j];
+                if (PV_FP8) x[j] *= sc4[dt][r4][j];
+                x[j] += mn4[dt][r4][j];
             }
             v2u pk;
             if (p.out_dtype == DT_F16) {
@@ -1254,7 +1275,8 @@ sage_attn_kernel(const AttnParams p)
             *reinterpret_cast<v2u *>(obuf + n * (D * 2) + Q * 16 + (q8 & 1) * 8) = pk;
         }
     }
-    __syncthreads();
+    // each wave transposes through its OWN 32-row region: its ds_writes and ds_reads execute in order, no workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
         constexpr int LPR = D * 2 / 16;          // lanes per row (16 B each)
         constexpr int RPP = 64 / LPR;            // rows per pass
