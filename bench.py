@@ -67,8 +67,9 @@ CONFIGS = {
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
 # HBM bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-# gfx950 correction per MI355X_MICROARCH.md); see profiles/r1_run48_pmc_c3_steady.txt
-PMC_TRAFFIC_BYTES = {"c3": 348.5e6}
+# gfx950 correction per MI355X_MICROARCH.md); see profiles/r2_run_m_pmc_c3.txt (FETCH_SIZE / WRITE_SIZE are in KiB: c3 = (2 x 105481 + 131072) KiB), _c5, _c2
+PMC_TRAFFIC_BYTES = {"c3": 350.2e6, "c5": 602.4e6, "c2": 205.2e6}
+ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6}
 
 
 def blended_peak(pv: str) -> float:
@@ -374,7 +375,7 @@ def main():
                    "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world} (shard.shard_bh of the global batch), no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get(args.config),
-                     "traffic_note": "HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), algorithmic 335.5e6" if args.config in PMC_TRAFFIC_BYTES else None,
+                     "traffic_note": ("HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r2_run_m_pmc_*.txt), algorithmic %.4g" % ALGO_BYTES[args.config]) if args.config in PMC_TRAFFIC_BYTES else None,
                      "kernel": "sage_attn_kernel", "avg_launch_ms": round(kern_ms, 4),
                      "peak_note": "harmonic blend of the dense MFMA peaks of the two halves: INT8 5.0 POPS (QK^T) and " + ("FP8 5.0 PF (MX-scaled instruction)" if cfg["pv"] == "fp8" else "FP16 2.5 PF") + " (PV)"},
         "end_to_end": {"ms_per_call": round(wall_e / e2e_steps * 1e3, 4),
