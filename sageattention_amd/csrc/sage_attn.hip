@@ -60,6 +60,12 @@
 #ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
 #define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
 #endif
+#ifndef SAGE_PIPE16     // the software-pipelined steady-state loop for FP16 PV as well
+#define SAGE_PIPE16 1
+#endif
+#ifndef SAGE_PIPE16_ORDER
+#define SAGE_PIPE16_ORDER 1
+#endif
 #ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
 #define SAGE_ASMDMA 1   // M0 write per image, inst_offset for the second piece) instead of four builtins with 64-bit VGPR addresses
 #endif
@@ -1179,6 +1185,272 @@ sage_attn_kernel(const AttnParams p)
 #undef A_PKLO
 #undef A_PKHI
 #undef A_PV
+#undef A_QK0
+#undef A_QK
+#undef A_FENCE
+        } else
+#endif
+#if SAGE_PIPE && SAGE_PIPE16
+        if constexpr (!PV_FP8 && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
+            // ---- software-pipelined steady state, FP16 PV --------------------------------------------------------------------
+            // Same structure as the FP8 loop above; differences:
+            //  * PV(t-1) is 4 x DT v_mfma_f32_32x32x16_f16 whose V fragments do not fit in registers next to two score tiles,
+            //    so they are read from LDS as they are needed, one 32-channel tile (4 x ds_read_b128) ahead of its MFMAs;
+            //  * V(t-1) must therefore stay in LDS through iteration t.  The 3-slot ring still suffices because a slot's K and
+            //    V regions are filled separately: at the top of iteration t the LDS-DMA brings K(t+2) into the K region of
+            //    slot (t+2)%3 (K(t-1), read in iteration t-2, is dead) and V(t+1) into the V region of slot (t+1)%3 (V(t-2),
+            //    read in iteration t-1, is dead); K(t+1) and V(t-1) were requested one and two iterations ago.
+#define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define A_FENCE()          asm volatile("" ::: "memory")
+            if (it < n_steady) {
+                v16i sA[2], sB[2];
+                {
+                    const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
+                    v4i kf0[2][C::KSTEPS];
+#pragma unroll
+                    for (int sb = 0; sb < 2; sb++) {
+                        const int krow = sb * 32 + n;
+#pragma unroll
+                        for (int kk = 0; kk < C::KSTEPS; kk++)
+                            kf0[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < C::KSTEPS; kk++)
+#pragma unroll
+                        for (int sb = 0; sb < 2; sb++)
+                            sA[sb] = kk == 0 ? mfma_i8_first(kf0[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf0[sb][kk], qf[kk], sA[sb], 0, 0, 0);
+                }
+                v4i pA[4], pB[4];                  // P of a tile as fp16 pairs: [chunk of 16 keys][word] = B operands of the PV MFMAs
+#pragma unroll
+                for (int c = 0; c < 4; c++) { pA[c] = v4i{0, 0, 0, 0}; pB[c] = v4i{0, 0, 0, 0}; }
+                const float sm26 = p.sm_scale_log2 * kSUnit;
+                static_assert(KP / 4 == 1 || KP / 4 == 2, "asm LDS-DMA: one or two K pieces per wave");
+                static_assert(VP / 4 == 2 * (KP / 4), "fp16 V image = two K tiles");
+                const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+                const unsigned voff16 = lane * 16;
+                const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
+                float alpha_p = 1.0f;
+                auto rescale = [&]() {
+                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
+#pragma unroll
+                        for (int dt = 0; dt < C::DT; dt++)
+#pragma unroll
+                            for (int i = 0; i < 16; i++) o[dt][i] *= alpha_p;
+                    }
+                };
+                bool first = true;                 // no previous tile yet: P = 0 against the (finite) V of the current slot
+                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
+                    rescale();
+                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                    const int prv = first ? cur : nn;                 // slot of tile t-1 = (cur + 2) % 3
+                    first = false;
+                    const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
+                    const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    {   // LDS-DMA: K(t+2) -> K region of slot nn, V(t+1) -> V region of slot nxt (SGPR-base form, see the FP8 loop)
+                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
+                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
+                        const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
+                        const unsigned ldv = lds_base + nxt * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
+                        unsigned keep;
+                        if constexpr (KP / 4 == 2)
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %7, %4\n\tglobal_load_lds_dwordx4 %7, %4 offset:1024\n\t"
+                                         "global_load_lds_dwordx4 %7, %4 offset:2048\n\tglobal_load_lds_dwordx4 %7, %4 offset:3072\n\t"
+                                         "s_mov_b32 m0, %0"
+                                         : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                        else
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %1, %2\n\t"
+                                         "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                                         "global_load_lds_dwordx4 %6, %3\n\tglobal_load_lds_dwordx4 %6, %3 offset:1024\n\t"
+                                         "s_mov_b32 m0, %0"
+                                         : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                    }
+                    float cs[2];
+                    cs[0] = sm26 * (qsc * ksc[0][0]);
+                    cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
+                    // V fragments of tile t-1, one 32-channel tile at a time (two register sets, alternating)
+                    v4i vfa[4], vfb[4];
+                    auto read_v = [&](int dt, v4i (&vf)[4]) {
+                        const int drow = dt * 32 + n;
+                        const unsigned char *vr = vsp + drow * 128;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) vf[c] = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                    };
+                    read_v(0, vfa);
+                    A_FENCE();
+                    // ---- row maximum of S(t) (plain code) ----
+                    int mx0 = INT_MIN, mx1 = INT_MIN;
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
+                            else mx0 = max(mx0, sc[u][i]);
+                        }
+                    float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
+                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
+                    const float m_new = fmaxf(m_run, pair_max(mxc));
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    A_FENCE();
+                    if constexpr (C::DT > 1) read_v(1, vfb);
+                    A_FENCE();
+
+                    float rs0 = 0.0f, rs1 = 0.0f;
+                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32: bias sub, scale fma, exp2, row-sum add, fp16 pack
+                        const int c = h >> 2, j0 = (h & 3) * 2;
+                        const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
+                        float t0, t1;
+                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
+                                     "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
+                                     "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+                                     "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
+                                     "v_cvt_pk_f16_f32 %4, %2, %3"
+                                     : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=v"(pc[c][h & 3])
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                    };
+                    v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
+                    auto read_k = [&](int sb, v4i (&kf)[C::KSTEPS]) {
+                        const int krow = sb * 32 + n;
+#pragma unroll
+                        for (int kk = 0; kk < C::KSTEPS; kk++)
+                            kf[kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
+                    };
+                    auto pv4 = [&](int dt, v4i (&vf)[4], int c) { A_PV16(o[dt], vf[c], pp[c]); };
+                    auto qk_next = [&](int sb, int kk) {
+                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
+                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
+                    };
+                    if constexpr (C::DT == 4) {
+                        // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
+                        // Two 32-channel tiles are in flight and their MFMAs alternate, so consecutive MFMAs never share an
+                        // accumulator (a dependent MFMA issued behind other instructions waits for the full write-back).
+#if SAGE_PIPE16_ORDER == 0
+                        pv4(0, vfa, 0); grp(0);
+                        pv4(0, vfa, 1); grp(1);
+                        pv4(0, vfa, 2); pv4(0, vfa, 3); grp(2);
+                        A_FENCE(); read_v(2, vfa); A_FENCE();
+                        pv4(1, vfb, 0); grp(3);
+                        pv4(1, vfb, 1); grp(4);
+                        pv4(1, vfb, 2); pv4(1, vfb, 3); grp(5);
+                        A_FENCE(); read_v(3, vfb); A_FENCE();
+                        pv4(2, vfa, 0); grp(6);
+                        pv4(2, vfa, 1); grp(7);
+                        pv4(2, vfa, 2); pv4(2, vfa, 3); grp(8);
+                        A_FENCE(); read_k(0, kfa); A_FENCE();
+                        pv4(3, vfb, 0); grp(9);
+                        pv4(3, vfb, 1); grp(10);
+                        pv4(3, vfb, 2); pv4(3, vfb, 3); grp(11);
+                        A_FENCE(); read_k(1, kfb); A_FENCE();
+                        qk_next(0, 0); qk_next(0, 1); grp(12);
+                        qk_next(0, 2); qk_next(0, 3); grp(13);
+                        qk_next(1, 0); qk_next(1, 1); grp(14);
+                        qk_next(1, 2); qk_next(1, 3); grp(15);
+#else
+                        pv4(0, vfa, 0); grp(0);
+                        pv4(1, vfb, 0); grp(1);
+                        pv4(0, vfa, 1); pv4(1, vfb, 1); grp(2);
+                        pv4(0, vfa, 2); grp(3);
+                        pv4(1, vfb, 2); grp(4);
+                        pv4(0, vfa, 3);
+                        A_FENCE(); read_v(2, vfa); A_FENCE();
+                        pv4(1, vfb, 3);
+                        A_FENCE(); read_v(3, vfb); A_FENCE();
+                        grp(5); grp(6);
+                        pv4(2, vfa, 0); grp(7);
+                        pv4(3, vfb, 0); grp(8);
+                        pv4(2, vfa, 1); pv4(3, vfb, 1); grp(9);
+                        pv4(2, vfa, 2); grp(10);
+                        pv4(3, vfb, 2);
+                        pv4(2, vfa, 3);
+                        A_FENCE(); read_k(0, kfa); A_FENCE();
+                        pv4(3, vfb, 3);
+                        A_FENCE(); read_k(1, kfb); A_FENCE();
+                        grp(11); grp(12);
+                        qk_next(0, 0); qk_next(1, 0); grp(13);
+                        qk_next(0, 1); qk_next(1, 1); grp(14);
+                        qk_next(0, 2); qk_next(1, 2); grp(15);
+                        qk_next(0, 3); qk_next(1, 3);
+#endif
+                    } else {                         // D = 64: 8 PV + 4 QK^T MFMAs
+                        pv4(0, vfa, 0); grp(0);
+                        pv4(0, vfa, 1); grp(1);
+                        pv4(0, vfa, 2); grp(2);
+                        pv4(0, vfa, 3); grp(3);
+                        A_FENCE(); read_k(0, kfa); A_FENCE();
+                        pv4(1, vfb, 0); grp(4);
+                        pv4(1, vfb, 1); grp(5);
+                        pv4(1, vfb, 2); grp(6);
+                        pv4(1, vfb, 3); grp(7);
+                        A_FENCE(); read_k(1, kfb); A_FENCE();
+                        grp(8); grp(9);
+                        qk_next(0, 0); grp(10); grp(11);
+                        qk_next(0, 1); grp(12);
+                        qk_next(1, 0); grp(13); grp(14);
+                        qk_next(1, 1); grp(15);
+                    }
+                    A_FENCE();
+                    float ksc_next[NH][2];
+                    load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
+                    l_run = l_run * alpha + (rs0 + rs1);
+                    ksc[0][0] = ksc_next[0][0];
+                    ksc[0][1] = ksc_next[0][1];
+                    cur = nxt;
+                    alpha_p = alpha;
+                    it++;
+                };
+                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
+                    body(sA, sB, pA, pB);
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                    sA[0] = sB[0]; sA[1] = sB[1];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pA[c] = pB[c];
+                }
+#pragma nounroll
+                while (it < n_steady) {
+                    body(sA, sB, pA, pB);
+                    body(sB, sA, pB, pA);
+                }
+                // drain: PV of the last pipelined tile (its V is in slot (cur + 2) % 3); V(it+1) is requested so that the general
+                // iteration finds tile it+1 "in flight" as a whole; then tile `it` must be complete and every wave past its reads
+                rescale();
+                {
+                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                    const int prv = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                    const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
+                    unsigned char *vsn = smem + nxt * C::STAGE_BYTES + C::K_TILE_BYTES;
+                    const unsigned char *vt = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES;
+#pragma unroll
+                    for (int i = 0; i < VP / 4; i++) {
+                        const int pc_ = wave * (VP / 4) + i;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc_ * 1024 + lane * 16),
+                                                         (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; dt++) {
+                        const int drow = dt * 32 + n;
+                        const unsigned char *vr = vsp + drow * 128;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const v4i a = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                            A_PV16(o[dt], a, pA[c]);
+                        }
+                    }
+                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VP / 4) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+#undef A_PV16
 #undef A_QK0
 #undef A_QK
 #undef A_FENCE
