@@ -242,6 +242,20 @@ SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, 
                                int B, int H, int L, int D, int64_t n_sb, int64_t n_sh, int64_t n_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl, int dtype, int first, void *stream);
 
+/* Split-KV merge.  A call whose grid would not fill the chip (few query blocks, long key range: cross-attention, decode-like
+ * shapes) is run as S chunks of the key range folded into the batch dimension (plus an optional ragged tail chunk from a
+ * second launch); every chunk leaves a normalised partial output (fp16) and its log-sum-exp (log2 domain, the value the
+ * attention entry points write to `lse`).  This op combines them in one pass:
+ *     m = max_s lse_s;  w_s = 2^(lse_s - m);  o = sum_s w_s o_s / sum_s w_s;  lse = m + log2(sum_s w_s)
+ * o_part [B, Hkv, S, group, L, D] fp16 contiguous (H = Hkv * group: the chunks are folded into the kv-head dimension),
+ * lse_part [B, Hkv, S, group, L]; o_tail [B, H, L, D] fp16 / lse_tail [B, H, L] nullable; o_out takes element strides;
+ * lse_out nullable.
+ * Replaces: nothing in the reference's kernels (they parallelise over query blocks only, qk_int_sv_f8_cuda_sm89.cuh:720-738);
+ * the combine is the one its sequence-parallel callers apply to `return_lse` results (core.py:782-786). */
+SAGE_API int sage_merge_split(const void *o_part, const float *lse_part, const void *o_tail, const float *lse_tail,
+                              void *o_out, float *lse_out, int B, int S, int H, int group, int L, int D,
+                              int64_t o_sb, int64_t o_sh, int64_t o_sl, int out_dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -357,4 +357,24 @@ SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, 
     return SAGE_OK;
 }
 
+SAGE_API int sage_merge_split(const void *o_part, const float *lse_part, const void *o_tail, const float *lse_tail,
+                              void *o_out, float *lse_out, int B, int S, int H, int group, int L, int D,
+                              int64_t o_sb, int64_t o_sh, int64_t o_sl, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(group > 0 && H % group == 0, "num heads (%d) must be divisible by the GQA group size (%d)", H, group);
+    SAGE_REQUIRE(o_part && lse_part && o_out, "null tensor pointer");
+    SAGE_REQUIRE((o_tail == nullptr) == (lse_tail == nullptr), "o_tail and lse_tail come together");
+    SAGE_REQUIRE(B > 0 && S > 0 && H > 0 && L > 0, "empty problem (B=%d S=%d H=%d L=%d)", B, S, H, L);
+    SAGE_REQUIRE(D > 0 && D % 8 == 0 && D <= 512, "head_dim must be a positive multiple of 8, at most 512 (got %d)", D);
+    SAGE_REQUIRE(out_dtype == SAGE_DTYPE_F16 || out_dtype == SAGE_DTYPE_BF16, "bad out_dtype %d", out_dtype);
+    SAGE_REQUIRE(aligned16(o_part) && aligned16(o_out) && (o_tail == nullptr || aligned16(o_tail)), "o tensors must be 16-byte aligned");
+    SAGE_REQUIRE(o_sb % 8 == 0 && o_sh % 8 == 0 && o_sl % 8 == 0, "o_out strides must be multiples of 8 elements");
+    sage::SplitMergeParams p{};
+    p.o_part = o_part; p.lse_part = lse_part; p.o_tail = o_tail; p.lse_tail = lse_tail; p.o_out = o_out; p.lse_out = lse_out;
+    p.B = B; p.S = S; p.H = H; p.L = L; p.D = D; p.group = group; p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl; p.dtype = out_dtype;
+    const hipError_t e = sage::launch_merge_split(p, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(SAGE_ELAUNCH, "sage_merge_split launch: %s", hipGetErrorString(e));
+    return SAGE_OK;
+}
+
 }  // extern "C"

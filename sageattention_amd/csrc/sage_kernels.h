@@ -116,4 +116,19 @@ struct MergeParams {
 };
 hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream);
 
+// ---- split-KV merge (one attention call computed as S (+1) key-range chunks) -------------------------------------------
+struct SplitMergeParams {
+    const void *o_part;       // fp16 [B, Hkv, S, group, L, D] contiguous (H = Hkv * group)
+    const float *lse_part;    // [B, Hkv, S, group, L] log2-domain log-sum-exp of each chunk (-inf: no visible key)
+    const void *o_tail;       // nullable fp16 [B, H, L, D]: one more chunk (ragged tail of the key range)
+    const float *lse_tail;    // [B, H, L]
+    void *o_out;              // fp16 / bf16, element strides below
+    float *lse_out;           // nullable [B, H, L] log2 domain
+    int B, S, H, L, D, group;
+    long o_sb, o_sh, o_sl;
+    int dtype;                // of o_out
+    int cpr_pad;              // set by the launcher
+};
+hipError_t launch_merge_split(const SplitMergeParams &p, hipStream_t stream);
+
 }  // namespace sage

@@ -75,6 +75,74 @@ merge_states_kernel(const MergeParams p)
     }
 }
 
+// ---- split-KV merge: S partial states of one attention call -> final output (one pass) ---------------------------------
+// The partial outputs are fp16 (11-bit significand: the merge adds no visible rounding for fp16 / bf16 results) in the
+// order the attention kernel wrote them with the KV chunks folded into the kv-head dimension: [B, Hkv, S, group, L, D]
+// (query head h = hk * group + g), and their log-sum-exps (log2 domain, as the kernel leaves them) [B, Hkv, S, group, L];
+// an optional (S+1)-th chunk (a ragged tail of the key range computed by a second launch) comes as [B, H, L, D] / [B, H, L].
+// One thread owns 8 channels of one row.
+template <int DT>
+__global__ void __launch_bounds__(256)
+merge_split_kernel(const SplitMergeParams p)
+{
+    const int cpr = p.D / 8;
+    const int cpr_pad = p.cpr_pad;
+    const long row = (long)blockIdx.x * (256 / cpr_pad) + threadIdx.x / cpr_pad;
+    const int c = threadIdx.x % cpr_pad;
+    if (row >= (long)p.B * p.H * p.L || c >= cpr) return;
+    const int c8 = c * 8;
+    const int l = (int)(row % p.L);
+    const long bh = row / p.L;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int hk = h / p.group, gq = h - hk * p.group;
+    const long HL = (long)p.group * p.L;                                              // chunk stride in rows
+    const long r0 = (((long)b * (p.H / p.group) + hk) * p.S) * HL + (long)gq * p.L + l;   // row of chunk 0
+    const float *la = p.lse_part + r0;                                                // + s * HL
+    const uint16_t *oa = reinterpret_cast<const uint16_t *>(p.o_part) + r0 * p.D + c8;
+    const bool tail = p.o_tail != nullptr;
+    const float lt = tail ? p.lse_tail[row] : -INFINITY;
+    float m = lt;
+    for (int s = 0; s < p.S; s++) m = fmaxf(m, la[(long)s * HL]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.0f;
+    auto add = [&](const uint16_t *src, float lse) {
+        if (lse == -INFINITY) return;                       // chunk with no visible key for this row
+        const float w = __builtin_amdgcn_exp2f(lse - m);
+        const v4u raw = *reinterpret_cast<const v4u *>(src);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned wd = raw[j >> 1];
+            acc[j] += w * f16_to_f32((uint16_t)((j & 1) ? (wd >> 16) : (wd & 0xffffu)));
+        }
+        wsum += w;
+    };
+    if (m != -INFINITY) {
+        for (int s = 0; s < p.S; s++) add(oa + (long)s * HL * p.D, la[(long)s * HL]);
+        if (tail) add(reinterpret_cast<const uint16_t *>(p.o_tail) + row * p.D + c8, lt);
+    }
+    const float inv = wsum > 0.0f ? 1.0f / wsum : 0.0f;
+    uint16_t *oo = reinterpret_cast<uint16_t *>(p.o_out) + (long)b * p.o_sb + (long)h * p.o_sh + (long)l * p.o_sl + c8;
+    v4u pk;
+#pragma unroll
+    for (int w = 0; w < 4; w++) pk[w] = (unsigned)st16<DT>(acc[2 * w] * inv) | ((unsigned)st16<DT>(acc[2 * w + 1] * inv) << 16);
+    *reinterpret_cast<v4u *>(oo) = pk;
+    if (p.lse_out != nullptr && c8 == 0) p.lse_out[row] = wsum > 0.0f ? m + __builtin_amdgcn_logf(wsum) : -INFINITY;   // v_log_f32 = log2
+}
+
+hipError_t launch_merge_split(const SplitMergeParams &p, hipStream_t stream)
+{
+    const long rows = (long)p.B * p.H * p.L;
+    if (rows <= 0) return hipSuccess;
+    SplitMergeParams q = p;
+    q.cpr_pad = 1;
+    while (q.cpr_pad < p.D / 8) q.cpr_pad *= 2;
+    if (q.cpr_pad > 64) return hipErrorInvalidValue;
+    const long rpb = 256 / q.cpr_pad;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (p.dtype == DT_F16) hipLaunchKernelGGL(merge_split_kernel<DT_F16>, grid, dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(merge_split_kernel<DT_BF16>, grid, dim3(256), 0, stream, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_states(const MergeParams &p, hipStream_t stream)
 {
     const long rows = (long)p.B * p.H * p.L;

@@ -719,6 +719,98 @@ def test_varlen_cu_q_differs_from_cu_k(oracle_mod, name):
     _assert_vs_oracle(f"varlen_cross/{name}", got, ref_o, dt)
 
 
+# ------------------------------------------------------------------------------------------------ split-KV
+def _split_oracle(O, q, k, v, dt, S, km):
+    """The split-KV algorithm restated with the oracle: quantise once (K mean, INT8 groups, per-channel FP8 V of the WHOLE
+    tensors), run the oracle's attention per key-range chunk with fp16 partial outputs, merge by log-sum-exp in float64."""
+    _, _, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=False, pv="f8",
+                                 qk_quant_gran="per_thread", km=km)
+    Lk = k.shape[2]
+    Lc = Lk // S
+    parts, lses = [], []
+    for s in range(S):
+        sl = slice(s * Lc, (s + 1) * Lc)
+        g0 = int(aux["gk"][s * Lc])
+        gk = (aux["gk"][sl] - g0).astype(np.int32)
+        ks = np.ascontiguousarray(aux["ks"][:, :, g0:g0 + int(gk.max()) + 1])
+        o_s, lse_s = O.attn(aux["q8"], np.ascontiguousarray(aux["k8"][:, :, sl]), np.ascontiguousarray(aux["v8"][:, :, sl]),
+                            aux["qs"], aux["gq"], ks, gk, causal=False, c=aux["c"], pv_mode=O.PV_F8_TWO_LEVEL, out_dtype=0,
+                            v_scale=aux["vs"], return_lse=True)
+        parts.append(util.f32(o_s, 0).astype(np.float64))
+        lses.append(lse_s.astype(np.float64))
+    lse = np.stack(lses)                                    # [S, B, H, L] log2 domain
+    m = lse.max(axis=0)
+    w = np.exp2(lse - m)
+    o = (np.stack(parts) * w[..., None]).sum(axis=0) / w.sum(axis=0)[..., None]
+    return o, m + np.log2(w.sum(axis=0))
+
+
+@pytest.mark.parametrize("case", [(1, 4, 4, 128, 4096, 128, 1, 4), (2, 4, 2, 200, 2048, 64, 0, 8), (1, 2, 1, 64, 1024, 128, 1, 2)],
+                         ids=["d128_bf16_s4", "gqa_d64_f16_s8", "gqa_d128_s2"])
+def test_split_kv_vs_split_oracle_and_sdpa(oracle_mod, case):
+    """Split-KV (chunks of the key range folded into the kv-head dimension + one log-sum-exp merge) against the same
+    algorithm restated with the oracle (tolerance of the kernel tests), against the unsplit call and fp32 SDPA
+    (the FP8 accuracy bounds: a different split changes which running maximum each P is rounded against)."""
+    B, Hq, Hkv, Lq, Lk, D, dt, S = case
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=500 + S, kbias=1.0)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=S)
+    o1, lse1 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=0)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean(kd))
+    ref, lse_ref = _split_oracle(oracle_mod, q, k, v, dt, S, km)
+    got = o.float().cpu().numpy()
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    REPORT[f"split_kv/{B}x{Hq}x{Lq}x{Lk}_d{D}_s{S}"] = dict(max_abs=err, max_o=scale)
+    assert np.isfinite(got).all() and err <= 2e-3 * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale
+    truth = util.sdpa_f32(qd, kd, vd, False).cpu().numpy()
+    for res in (got, o1.float().cpu().numpy()):
+        assert util.cos_sim(res, truth) >= 0.999
+    assert (lse - lse1).abs().max().item() <= 2e-2           # same quantity through two summation orders (+ fp8 noise on l)
+    with pytest.raises(ValueError):
+        sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, split_kv=7)
+
+
+def test_split_kv_auto_plan_and_merge_kernel_edge_cases():
+    """The planner (host logic) and the merge kernel alone: GQA chunk layout, a tail chunk, rows a chunk did not see (-inf)."""
+    from sageattention_amd import core, _cabi
+    assert core._split_kv_plan(1, 32, 128, 32768, False, None) == 16          # 32 workgroups, 512 tiles -> 16 chunks of 32 tiles
+    assert core._split_kv_plan(2, 32, 8192, 8192, False, None) == 0           # the grid already fills the chip
+    assert core._split_kv_plan(1, 32, 128, 32768, True, None) == 0            # causal calls are not split
+    assert core._split_kv_plan(1, 8, 128, 32768 + 32, False, None) == 0       # ragged key range
+    B, Hkv, group, S, L, D = 2, 2, 3, 4, 37, 64
+    H = Hkv * group
+    g = torch.Generator().manual_seed(9)
+    o_part = torch.randn(B, Hkv, S, group, L, D, generator=g).to(torch.float16).to(DEV)
+    lse_part = (3.0 * torch.randn(B, Hkv, S, group, L, generator=g)).to(DEV)
+    lse_part[0, 0, 1] = float("-inf")
+    lse_part[1, 1, :, 2, 5] = float("-inf")                                   # a row no chunk saw
+    o_tail = torch.randn(B, H, L, D, generator=g).to(torch.float16).to(DEV)
+    lse_tail = torch.randn(B, H, L, generator=g).to(DEV)
+    for with_tail in (False, True):
+        o = torch.empty(B, H, L, D, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
+        rc = _cabi.load().sage_merge_split(o_part.data_ptr(), lse_part.data_ptr(), o_tail.data_ptr() if with_tail else None,
+                                           lse_tail.data_ptr() if with_tail else None, o.data_ptr(), lse.data_ptr(), B, S, H, group, L, D,
+                                           o.stride(0), o.stride(1), o.stride(2), _cabi.DTYPE_BF16, torch.cuda.current_stream().cuda_stream)
+        _cabi.check(rc, "sage_merge_split")
+        torch.cuda.synchronize()
+        op = o_part.double().permute(2, 0, 1, 3, 4, 5).reshape(S, B, H, L, D)
+        lp = lse_part.double().permute(2, 0, 1, 3, 4).reshape(S, B, H, L)
+        if with_tail:
+            op, lp = torch.cat([op, o_tail.double()[None]]), torch.cat([lp, lse_tail.double()[None]])
+        m = lp.max(dim=0).values
+        w = torch.exp2(lp - m.clamp_min(-1e30))
+        w = torch.where(torch.isinf(lp), torch.zeros_like(w), w)
+        ws = w.sum(dim=0)
+        want = torch.where(ws[..., None] > 0, (op * w[..., None]).sum(dim=0) / ws[..., None].clamp_min(1e-300), torch.zeros_like(op[0]))
+        assert (o.double() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-6
+        want_lse = torch.where(ws > 0, m + torch.log2(ws.clamp_min(1e-300)), torch.full_like(m, float("-inf")))
+        fin = torch.isfinite(want_lse)
+        assert torch.equal(torch.isfinite(lse.double()), fin) and (lse.double()[fin] - want_lse[fin]).abs().max().item() <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ LSE merge / ring caller
 @pytest.mark.parametrize("dt,layout,D,L", [(0, "HND", 128, 333), (1, "NHD", 64, 130), (1, "HND", 96, 17)])
 def test_merge_states_matches_formula(dt, layout, D, L):

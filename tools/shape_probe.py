@@ -17,13 +17,16 @@ SHAPES = [  # name, B, Hq, Hkv, Lq, Lk, D, causal
     ("B=64 H=16 N=256 non-causal D=64", 64, 16, 16, 256, 256, 64, False),
     ("GQA 32/4 N=4096 causal", 2, 32, 4, 4096, 4096, 128, True),
     ("short q, long k: Lq=128 Lk=32768", 1, 32, 32, 128, 32768, 128, False),
+    ("short q, long k, split off", 1, 32, 32, 128, 32768, 128, False),
+    ("cross-attn B1 H16 Lq=1024 Lk=16384", 1, 16, 16, 1024, 16384, 128, False),
+    ("cross-attn B1 H16 Lq=1024 Lk=16384, split off", 1, 16, 16, 1024, 16384, 128, False),
 ]
 dev = torch.device("cuda:0")
 for name, B, Hq, Hkv, Lq, Lk, D, causal in SHAPES:
     q = torch.randn(B, Hq, Lq, D, device=dev, dtype=torch.bfloat16)
     k = torch.randn(B, Hkv, Lk, D, device=dev, dtype=torch.bfloat16)
     v = torch.randn(B, Hkv, Lk, D, device=dev, dtype=torch.bfloat16)
-    fn = lambda: sa.sageattn(q, k, v, is_causal=causal)
+    fn = (lambda: sa.sageattn(q, k, v, is_causal=causal, split_kv=0)) if "split off" in name else (lambda: sa.sageattn(q, k, v, is_causal=causal))
     t_end = time.perf_counter() + 0.2
     while time.perf_counter() < t_end:
         fn()
