@@ -379,13 +379,15 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
     if sm_scale is None:
         sm_scale = head_dim_og ** -0.5
-    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
     if pv_accum_dtype in ("fp32+fp32", "fp32+fp16") and smooth_v:
         warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")   # core.py:797-803
         smooth_v = False
     fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
     if fuse_q:
-        # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM)
+        # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM).
+        # (Running the V pre-pass on a side stream beside the K chain was measured and rejected: the two HBM-bound chains
+        #  slow each other down and the cross-stream joins cost more than the launch gaps they hide, 956 -> 1130 us at C3.)
+        km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
         km_s = _squeeze_km(km, tensor_layout)
         k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
         v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
@@ -398,6 +400,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
             o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
                                    return_lse, v_mean=vm)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
     q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)
     v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
