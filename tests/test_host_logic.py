@@ -73,3 +73,32 @@ def test_custom_ops_registered_with_fake_impl():
         assert lse.shape == (2, 4, 300) and lse.dtype == torch.float32
         lse0 = torch.ops.sageattention_gfx950.qk_int8_sv_f16_attn(q, k, v, o, qs, ks, None, 0, 0, 2, 32, 0.1, 0, 0)
         assert lse0.numel() == 0
+
+
+def test_split_kv_planner():
+    """Host logic of the split-KV route (core._split_kv_plan): when a call is split and into how many chunks."""
+    plan = core._split_kv_plan
+    assert plan(1, 32, 128, 32768, False, None) == 16          # 32 workgroups, 512 key tiles -> 16 chunks of 32 tiles
+    assert plan(1, 16, 1024, 16384, False, None) == 4          # 128 workgroups, 256 tiles: target 6 -> largest divisor of 256 below it
+    assert plan(2, 32, 8192, 8192, False, None) == 0           # the grid already fills the chip
+    assert plan(1, 32, 128, 32768, True, None) == 0            # causal calls are not split
+    assert plan(1, 8, 128, 32768 + 32, False, None) == 0       # ragged key range
+    assert plan(1, 8, 128, 2048, False, None) == 0             # short key range
+    assert plan(1, 8, 128, 4096, False, 0) == 0                # switched off
+    assert plan(1, 8, 128, 4096, False, 8) == 8                # forced
+    with pytest.raises(ValueError):
+        plan(1, 8, 128, 4096, False, 7)                        # does not divide the 64 key tiles
+
+
+def test_bench_rank_units_partition_the_global_problem():
+    """bench.py gives rank r the shard_bh slice of the global batch: the slices of all ranks are disjoint and cover it."""
+    B, Hq, Hkv, L, D = 3, 4, 2, 5, 8
+    q = torch.arange(B * Hq * L * D, dtype=torch.float32).reshape(B, Hq, L, D)
+    k = torch.arange(B * Hkv * L * D, dtype=torch.float32).reshape(B, Hkv, L, D)
+    for world in (1, 2, 4, 5):
+        seen_q, seen_k = [], []
+        for r in range(world):
+            qs, ks, vs, (lo, hi) = shard.shard_bh(q, k, k, r, world)
+            assert qs.shape == (1, (hi - lo) * (Hq // Hkv), L, D) and ks.shape == (1, hi - lo, L, D)
+            seen_q.append(qs.reshape(-1, L, D)); seen_k.append(ks.reshape(-1, L, D))
+        assert torch.equal(torch.cat(seen_q), q.reshape(-1, L, D)) and torch.equal(torch.cat(seen_k), k.reshape(-1, L, D))
