@@ -254,77 +254,6 @@ sage_attn_kernel(const AttnParams p)
     // ---- Q fragments (B operand of S^T = K Q^T), resident in VGPRs ---------------------------
     v4i qf[C::KSTEPS];
     float qsc;
-    if constexpr (QF == 0) {
-        const int8_t *qrow = reinterpret_cast<const int8_t *>(p.q) + q_off + (long)my_row * p.q_sl;
-        const bool ok = my_row < Lq;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            v4i z = {0, 0, 0, 0};
-#ifdef SAGE_HACK_NOQ         // timing experiment only: no Q loads
-            qf[ks] = v4i{lane, ks, lane * 3, 7};
-#elif defined(SAGE_HACK_QHOT) // timing experiment only: every workgroup reads the first 128 rows of the tensor (cache-hot, realistic values)
-            qf[ks] = *reinterpret_cast<const v4i *>(reinterpret_cast<const int8_t *>(p.q) + (long)(wave * 32 + n) * p.q_sl + 32 * ks + 16 * g);
-#else
-            qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
-#endif
-        }
-        // this lane's query-row scale (per-block / per-warp / per-thread granularity, see DESIGN.md)
-        int slot;
-        const int rin = wave * 32 + n;               // row inside the 128-row block
-        if (p.q_gran == QG_PER_BLOCK) slot = 0;
-        else if (p.q_gran == QG_PER_WARP32) slot = rin >> 5;
-        else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
-        else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
-        else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
-#ifdef SAGE_HACK_NOQ
-        qsc = 0.01f + 1e-6f * slot;
-#elif defined(SAGE_HACK_QHOT)
-        qsc = p.q_scale[slot];
-#else
-        qsc = qs_ptr[slot * qs_stride];
-#endif
-    } else {
-        // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
-        // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
-        // r, r+8, r+16, r+24 of the wave's 32-row tile, all 128 channels: lanes n = r (mod 8), both halves g.
-        constexpr int QDT = (QF == 1) ? DT_F16 : DT_BF16;
-        const uint16_t *qrow = reinterpret_cast<const uint16_t *>(p.q) + q_off + (long)my_row * p.q_sl;
-        const bool ok = my_row < Lq;
-        float x[C::KSTEPS][16];
-        float amax = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            v4u raw[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-            if (ok) {
-                raw[0] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g);
-                raw[1] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g + 8);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const unsigned w = raw[j >> 3][(j & 7) >> 1];
-                const float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
-                x[ks][j] = f;
-                amax = fmaxf(amax, fabsf(f));
-            }
-        }
-        amax = fmaxf(amax, __shfl_xor(amax, 8));
-        amax = fmaxf(amax, __shfl_xor(amax, 16));
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
-        const float sc = quant_scale(amax, QS_TRITON_THREAD);
-        const float y = quant_recip(sc);
-        qsc = sc;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            int q8[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton(x[ks][j], sc, y);
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                qf[ks][w] = (int)((unsigned)(q8[4 * w] & 0xff) | ((unsigned)(q8[4 * w + 1] & 0xff) << 8) |
-                                  ((unsigned)(q8[4 * w + 2] & 0xff) << 16) | ((unsigned)(q8[4 * w + 3] & 0xff) << 24));
-        }
-    }
-
     // ---- tile staging ------------------------------------------------------------------------
     const unsigned char *kbase = reinterpret_cast<const unsigned char *>(p.k) + k_off;
     const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v);
@@ -476,6 +405,80 @@ sage_attn_kernel(const AttnParams p)
         write_lds(0);
     }
     if (NSTAGE == 3 && n_iters > 1) issue_loads(std::false_type{}, 1, 1);
+    // The Q fragments are fetched AFTER the first tiles' LDS-DMA has been issued: hipcc waits vmcnt(0) at the first use of an
+    // ordinary VGPR load, and with the Q loads in front it did so after the first DMA instruction -- the Q round trip and the
+    // tiles' round trip ran one after the other in every workgroup's prologue.
+    if constexpr (QF == 0) {
+        const int8_t *qrow = reinterpret_cast<const int8_t *>(p.q) + q_off + (long)my_row * p.q_sl;
+        const bool ok = my_row < Lq;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ks++) {
+            v4i z = {0, 0, 0, 0};
+#ifdef SAGE_HACK_NOQ         // timing experiment only: no Q loads
+            qf[ks] = v4i{lane, ks, lane * 3, 7};
+#elif defined(SAGE_HACK_QHOT) // timing experiment only: every workgroup reads the first 128 rows of the tensor (cache-hot, realistic values)
+            qf[ks] = *reinterpret_cast<const v4i *>(reinterpret_cast<const int8_t *>(p.q) + (long)(wave * 32 + n) * p.q_sl + 32 * ks + 16 * g);
+#else
+            qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
+#endif
+        }
+        // this lane's query-row scale (per-block / per-warp / per-thread granularity, see DESIGN.md)
+        int slot;
+        const int rin = wave * 32 + n;               // row inside the 128-row block
+        if (p.q_gran == QG_PER_BLOCK) slot = 0;
+        else if (p.q_gran == QG_PER_WARP32) slot = rin >> 5;
+        else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
+        else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
+        else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
+#ifdef SAGE_HACK_NOQ
+        qsc = 0.01f + 1e-6f * slot;
+#elif defined(SAGE_HACK_QHOT)
+        qsc = p.q_scale[slot];
+#else
+        qsc = qs_ptr[slot * qs_stride];
+#endif
+    } else {
+        // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
+        // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
+        // r, r+8, r+16, r+24 of the wave's 32-row tile, all 128 channels: lanes n = r (mod 8), both halves g.
+        constexpr int QDT = (QF == 1) ? DT_F16 : DT_BF16;
+        const uint16_t *qrow = reinterpret_cast<const uint16_t *>(p.q) + q_off + (long)my_row * p.q_sl;
+        const bool ok = my_row < Lq;
+        float x[C::KSTEPS][16];
+        float amax = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ks++) {
+            v4u raw[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (ok) {
+                raw[0] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g);
+                raw[1] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const unsigned w = raw[j >> 3][(j & 7) >> 1];
+                const float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                x[ks][j] = f;
+                amax = fmaxf(amax, fabsf(f));
+            }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 8));
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        const float sc = quant_scale(amax, QS_TRITON_THREAD);
+        const float y = quant_recip(sc);
+        qsc = sc;
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ks++) {
+            int q8[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton(x[ks][j], sc, y);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                qf[ks][w] = (int)((unsigned)(q8[4 * w] & 0xff) | ((unsigned)(q8[4 * w + 1] & 0xff) << 8) |
+                                  ((unsigned)(q8[4 * w + 2] & 0xff) << 16) | ((unsigned)(q8[4 * w + 3] & 0xff) << 24));
+        }
+    }
+
     ring_wait(NSTAGE == 3 && n_iters > 1);
 
     int cur = 0;
