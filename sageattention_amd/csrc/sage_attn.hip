@@ -63,7 +63,7 @@
 #ifndef SAGE_PIPE16     // the software-pipelined steady-state loop for FP16 PV as well
 #define SAGE_PIPE16 1
 #endif
-#ifndef SAGE_PIPE16_ORDER
+#ifndef SAGE_PIPE16_ORDER   // 1: the PV MFMAs of two 32-channel tiles alternate (a third fragment set for a longer LDS lead measured no better)
 #define SAGE_PIPE16_ORDER 1
 #endif
 #ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
