@@ -1025,7 +1025,11 @@ sage_attn_kernel(const AttnParams p)
                     const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
                     const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
+#ifdef SAGE_HACK_NOVMWAIT     // timing experiment only (racy): how much does the wait for tile t+1 cost?
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
                     if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
                     if constexpr ((SAGE_ABL & 8) == 0) {
 #if SAGE_ASMDMA
