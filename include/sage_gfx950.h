@@ -230,6 +230,20 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
 
+/* The same kernel over a key range split into kv_split chunks of Lk_chunk keys each (a whole number of 64-key tiles), folded
+ * into the kv-head dimension: k / k_scale / v_image / v_scale / v_mean are the operands of the unsplit call viewed as
+ * [B, Hkv * kv_split, Lk_chunk, ...] (zero-copy for head-major storage; v_scale / v_mean repeated per chunk), q is the
+ * unsplit query tensor [B, Hq, Lq, D] (read in place by every chunk), o_part [B, Hq * kv_split, Lq, D] and lse_part
+ * [B, Hq * kv_split, Lq] receive one normalised partial state per chunk in the order sage_merge_split expects
+ * (query head index = (hk * kv_split + chunk) * group + g).  is_causal masks key > query row in GLOBAL key coordinates
+ * (chunks behind the diagonal produce lse = -inf).  Replaces nothing in the reference (see sage_merge_split). */
+SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
+                                           const float *k_scale, const float *v_scale, const float *v_mean,
+                                           int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
+                                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+
 /* Merge a partial attention state into a running FP32 state by log-sum-exp (natural log), in place:
  *   m = max(lse_acc, lse_new); w_a = e^(lse_acc-m); w_b = e^(lse_new-m);
  *   o_acc = (o_acc w_a + o_new w_b) / (w_a + w_b);  lse_acc = m + log(w_a + w_b)

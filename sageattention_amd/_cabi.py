@@ -47,6 +47,8 @@ SYMBOLS = {
                                                 _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_attn_fused_q_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+    "sage_attn_fused_q_pv_f8_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+                                              _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_merge_states": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _P]),
     "sage_merge_split": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
 }

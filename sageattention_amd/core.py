@@ -116,10 +116,10 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
 def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override: Optional[int]) -> int:
     """Number of key-range chunks S for a call whose grid would not fill the chip (0 = no split).  The reference kernels
     parallelise over (batch, head, 128-row q block) only, so few query rows against a long key range (cross-attention,
-    decode-like shapes) leave most of the 256 CUs idle; here such a call runs as S chunks of Lk/S keys folded into the
-    kv-head dimension and one merge by log-sum-exp.  Chunks are whole numbers of 64-key tiles (the quantisation groups and
-    the V image tiles are unchanged by the fold), so only S | Lk/64 is considered; causal calls are not split."""
-    if override == 0 or is_causal or Lk % 64 != 0:
+    decode-like shapes) leave most of the 256 CUs idle.  Such a call runs as
+    S chunks of Lk/S keys folded into the kv-head dimension and one merge by log-sum-exp.  Chunks are whole numbers of
+    64-key tiles (the quantisation groups and the V image tiles are unchanged by the fold), so only S | Lk/64 is considered."""
+    if override == 0 or Lk % 64 != 0:
         return 0
     ntk = Lk // 64
     if override:
@@ -127,42 +127,44 @@ def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override:
             raise ValueError(f"split_kv={override} must be >= 2 and divide the number of 64-key tiles ({ntk})")
         return override
     n_wg = B * Hq * ((Lq + 127) // 128)
-    if n_wg > 128 or ntk < 64:                         # the grid already covers half the chip, or the key range is short
+    if is_causal:
+        # Causal calls are split only on request (split_kv=S; the mask then runs in global key coordinates).  Measured for the
+        # case it could help -- one partial wave of workgroups, B=1 H=8 N=8192: 179 us unsplit, 199 us with S=4 -- the partial
+        # outputs' extra pass through HBM and the merge cost more than the better balance returns (profiles/r2_run_z_shape_probe.txt).
         return 0
-    target = max(2, min(ntk // 32, -(-768 // n_wg)))   # chunks of >= 32 tiles, about three workgroups per CU
+    else:
+        if n_wg > 128 or ntk < 64:                     # the grid already covers half the chip, or the key range is short
+            return 0
+        target = max(2, min(ntk // 32, -(-768 // n_wg)))   # chunks of >= 32 tiles, about three workgroups per CU
     S = max(d for d in range(1, target + 1) if ntk % d == 0)
     return S if S >= 2 else 0
 
 
 @torch.compiler.disable
-def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, sm_scale_log2, S, return_lse, v_mean=None):
+def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, S, return_lse, v_mean=None):
     """Split-KV route of the fused-Q FP8 attention: the key range in S chunks folded into the kv-head dimension (zero-copy
-    views of the INT8 K, its scales and the V image; Q is repeated per chunk, it is small here by construction), partial
-    outputs in fp16 + log2-domain log-sum-exps, one ``sage_merge_split`` pass."""
-    B, Hq, Lq, D, _, _, _ = _dims(q, tensor_layout)
+    views of the INT8 K, its scales and the V image; Q is read in place by every chunk), partial outputs in fp16 +
+    log2-domain log-sum-exps, one ``sage_merge_split`` pass."""
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q, tensor_layout)
     _, Hkv, Lk, _, _, _, _ = _dims(k_int8, tensor_layout)
     group, Lc = Hq // Hkv, Lk // S
-    qh = q if tensor_layout == "HND" else q.transpose(1, 2)
-    q_rep = qh.reshape(B, Hkv, 1, group, Lq, D).expand(B, Hkv, S, group, Lq, D).reshape(B, Hkv * S * group, Lq, D).contiguous()
     k_store = k_int8 if tensor_layout == "HND" else k_int8.permute(0, 2, 1, 3)      # head-major storage (quant._quant)
     assert k_store.is_contiguous() and v_image.is_contiguous() and k_scale.is_contiguous()
     k_f = k_store.view(B, Hkv * S, Lc, D)
     ks_f = k_scale.view(B, Hkv * S, -1)
     vs_f = v_scale.repeat_interleave(S, dim=1)
     vm_f = None if v_mean is None else v_mean.repeat_interleave(S, dim=1)
-    Hq2, Hkv2 = Hkv * S * group, Hkv * S
-    o_part = torch.empty((B, Hq2, Lq, D), dtype=torch.float16, device=q.device)
-    lse_part = torch.empty((B, Hq2, Lq), dtype=torch.float32, device=q.device)
-    _, _, _, _, q_sb, q_sh, q_sl = _dims(q_rep, "HND")
+    o_part = torch.empty((B, Hq * S, Lq, D), dtype=torch.float16, device=q.device)
+    lse_part = torch.empty((B, Hq * S, Lq), dtype=torch.float32, device=q.device)
     _, _, _, _, k_sb, k_sh, k_sl = _dims(k_f, "HND")
     _, _, _, _, p_sb, p_sh, p_sl = _dims(o_part, "HND")
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
     lib = _cabi.load()
-    rc = lib.sage_attn_fused_q_pv_f8(
-        _p(q_rep), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
-        B, Hq2, Hkv2, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
-        0, float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
-    _cabi.check(rc, "sage_attn_fused_q_pv_f8 (split-KV)")
+    rc = lib.sage_attn_fused_q_pv_f8_split(
+        _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
+        B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
+        int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
+    _cabi.check(rc, "sage_attn_fused_q_pv_f8_split")
     o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
@@ -394,8 +396,8 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
         n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
         if n_split:
-            o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, _sm_log2(sm_scale),
-                                         n_split, return_lse, v_mean=vm)
+            o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal,
+                                         _sm_log2(sm_scale), n_split, return_lse, v_mean=vm)
         else:
             o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
                                    return_lse, v_mean=vm)

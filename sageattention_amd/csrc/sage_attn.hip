@@ -230,7 +230,10 @@ sage_attn_kernel(const AttnParams p)
         ks_ptr = p.k_scale + (long)p.cu_ks[b] * p.Hkv + hk;           // [sum nblk, Hkv]
         ks_tstride = p.Hkv;
     } else {
-        q_off = (long)b * p.q_sb + (long)h * p.q_sh;
+        // split-KV (p.kv_split = S > 1): the key range is folded into the kv-head dimension, kv head hk = hk0 * S + chunk and query
+        // head h = hk * group + g; the query rows are those of head hk0 * group + g (read in place, no per-chunk copy of Q)
+        const int hq = p.kv_split > 1 ? (hk / p.kv_split) * p.group + (h - hk * p.group) : h;
+        q_off = (long)b * p.q_sb + (long)hq * p.q_sh;
         k_off = (long)b * p.k_sb + (long)hk * p.k_sh;
         o_off = (long)b * p.o_sb + (long)h * p.o_sh;
         const int ntk = (Lk + BLKK - 1) / BLKK;
@@ -244,10 +247,15 @@ sage_attn_kernel(const AttnParams p)
 
     const int row0 = qblk * BLKQ + wave * 32;        // first query row of this wave
     const int my_row = row0 + n;
+    // causal mask in the chunk's key coordinates (split-KV: this workgroup sees keys kchunk0 .. kchunk0 + Lk - 1 as 0 .. Lk - 1):
+    // key <= row  <=>  local key <= row - kchunk0
+    const int kchunk0 = (CAUSAL && p.kv_split > 1 && p.cu_q == nullptr) ? (hk % p.kv_split) * Lk : 0;
+    const int crow0 = row0 - kchunk0, cmy_row = my_row - kchunk0;
     const int ntk_all = (Lk + BLKK - 1) / BLKK;      // 64-key images that exist
     int n_iters = (Lk + KT - 1) / KT;
     if (CAUSAL) {
-        const int lim = (qblk * BLKQ + BLKQ + KT - 1) / KT;
+        int lim = (qblk * BLKQ + BLKQ - kchunk0 + KT - 1) / KT;      // <= 0: the whole chunk lies behind the diagonal
+        lim = lim > 0 ? lim : 0;
         n_iters = lim < n_iters ? lim : n_iters;
     }
 
@@ -503,7 +511,7 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             const int key0 = it * KT + hh * BLKK;
-            if (!STEADY && key0 < Lk && (!CAUSAL || key0 <= row0 + 31)) nact = hh + 1;
+            if (!STEADY && key0 < Lk && (!CAUSAL || key0 <= crow0 + 31)) nact = hh + 1;
         }
         // ---- attn_mask (Triton-named API only; attn_qk_int8_per_block.py:31-51): additive term per
         //      score in the log2 domain.  bool: 0 / -1e6, and a tile whose whole 128x64 mask block is
@@ -535,7 +543,7 @@ sage_attn_kernel(const AttnParams p)
             const unsigned char *ks = smem + cur * C::STAGE_BYTES;
             const unsigned char *vs = ks + C::K_TILE_BYTES;
             const int last_key = it * KT + nact * BLKK - 1;
-            const bool full = STEADY || ((MASK == 0) && (nact == NH) && !(CAUSAL && last_key > row0) && (last_key < Lk));
+            const bool full = STEADY || ((MASK == 0) && (nact == NH) && !(CAUSAL && last_key > crow0) && (last_key < Lk));
 
             // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
             v16i s[NS];
@@ -616,7 +624,7 @@ sage_attn_kernel(const AttnParams p)
                         if (sb < 2 * nact) {
                             const float cc = cs[sb >> 1][(KTHREAD && (i & 2)) ? 1 : 0];
                             const int key = it * KT + sb * 32 + crow(i, g);
-                            const bool ok = (key < Lk) && (!CAUSAL || key <= my_row);
+                            const bool ok = (key < Lk) && (!CAUSAL || key <= cmy_row);
                             if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i] - OFF);
                             else mx = fmaxf(mx, ok ? __builtin_fmaf(sfl(s[sb][i]), cc, -OFF) : -INFINITY);
                         }
@@ -654,7 +662,7 @@ sage_attn_kernel(const AttnParams p)
                         v = __builtin_amdgcn_exp2f(__builtin_fmaf(sfl(s[sb][i]), cc, -m_new));
                         if constexpr (decltype(masked)::value) {
                             const int key = it * KT + sb * 32 + crow(i, g);
-                            const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= my_row);
+                            const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= cmy_row);
                             v = ok ? v : 0.0f;
                         }
                     }
@@ -948,7 +956,11 @@ sage_attn_kernel(const AttnParams p)
 #ifdef SAGE_HACK_NODIAG      // timing experiment only (wrong results): diagonal tiles run unmasked through the steady loop
         { int ns2 = Lk / KT - 2; n_steady = ns2 < n_iters ? ns2 : n_iters; }
 #else
-        if (CAUSAL) n_steady = n_steady < 2 * qblk ? n_steady : 2 * qblk;
+        if (CAUSAL) {                                  // unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk - kchunk0
+            int nd = (qblk * BLKQ - kchunk0) / KT;
+            nd = nd > 0 ? nd : 0;
+            n_steady = n_steady < nd ? n_steady : nd;
+        }
 #endif
 
 #if SAGE_PIPE

@@ -301,14 +301,15 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                        is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order);
 }
 
-SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
-                                     const float *k_scale, const float *v_scale, const float *v_mean,
-                                     int B, int Hq, int Hkv, int Lq, int Lk, int D,
-                                     int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
-                                     int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+static int fused_q_common(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                          const float *k_scale, const float *v_scale, const float *v_mean,
+                          int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                          int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                          int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                          int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream)
 {
     SAGE_REQUIRE(q && k && v_image && o && k_scale && v_scale, "null tensor pointer");
+    SAGE_REQUIRE(kv_split >= 0 && (kv_split <= 1 || Hkv % kv_split == 0), "kv_split (%d) must divide the folded kv-head count (%d)", kv_split, Hkv);
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0 && Lk > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d Lk=%d)", B, Hq, Hkv, Lq, Lk);
     SAGE_REQUIRE(Hq % Hkv == 0, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
@@ -332,8 +333,34 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
     p.nks = ((Lk + sage::BLKK - 1) / sage::BLKK) * 4;
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = sm_scale_log2;
+    p.kv_split = kv_split;
     return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, static_cast<hipStream_t>(stream)),
                         "sage_attn_fused_q launch");
+}
+
+SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                     const float *k_scale, const float *v_scale, const float *v_mean,
+                                     int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                     int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                     int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+{
+    return fused_q_common(q, k, v_image, o, lse, k_scale, v_scale, v_mean, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream);
+}
+
+SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
+                                           const float *k_scale, const float *v_scale, const float *v_mean,
+                                           int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
+                                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
+    SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
+    SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);
+    return fused_q_common(q, k, v_image, o_part, lse_part, k_scale, v_scale, v_mean, B, Hq * kv_split, Hkv * kv_split, Lq, Lk_chunk, D,
+                          q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream);
 }
 
 SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,

@@ -34,6 +34,7 @@ struct AttnParams {
     int nqs, nks;             // scale slots per (b,h) for q / k (dense)
     int qs_per_blk;           // q scale slots per 128-row block
     int q_gran;               // QG_*
+    int kv_split;             // > 1: split-KV, the key range of a head is folded into the kv-head dimension (dense, fused-Q kernels)
     int ks_shift;             // k scale groups span 64 << ks_shift keys (1: the sm90 kernels' 128-key groups, core.py:964-970)
     int out_dtype;            // DT_F16 / DT_BF16
     long lse_sh;              // varlen lse head stride (unused for dense)

@@ -720,51 +720,58 @@ def test_varlen_cu_q_differs_from_cu_k(oracle_mod, name):
 
 
 # ------------------------------------------------------------------------------------------------ split-KV
-def _split_oracle(O, q, k, v, dt, S, km):
+def _split_oracle(O, q, k, v, dt, S, km, causal=False):
     """The split-KV algorithm restated with the oracle: quantise once (K mean, INT8 groups, per-channel FP8 V of the WHOLE
-    tensors), run the oracle's attention per key-range chunk with fp16 partial outputs, merge by log-sum-exp in float64."""
-    _, _, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=False, pv="f8",
+    tensors), run the oracle's attention per key-range chunk with fp16 partial outputs, merge by log-sum-exp in float64.
+    Causal: chunk s holds keys s*Lc .., so only the query rows >= s*Lc see it, top-left aligned against the chunk."""
+    _, _, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
                                  qk_quant_gran="per_thread", km=km)
+    B, Hq, Lq, D = q.shape
     Lk = k.shape[2]
     Lc = Lk // S
-    parts, lses = [], []
+    parts = np.zeros((S, B, Hq, Lq, D), dtype=np.float64)
+    lse = np.full((S, B, Hq, Lq), -np.inf, dtype=np.float64)
     for s in range(S):
         sl = slice(s * Lc, (s + 1) * Lc)
+        r0 = s * Lc if causal else 0
+        if r0 >= Lq:
+            continue
         g0 = int(aux["gk"][s * Lc])
         gk = (aux["gk"][sl] - g0).astype(np.int32)
         ks = np.ascontiguousarray(aux["ks"][:, :, g0:g0 + int(gk.max()) + 1])
-        o_s, lse_s = O.attn(aux["q8"], np.ascontiguousarray(aux["k8"][:, :, sl]), np.ascontiguousarray(aux["v8"][:, :, sl]),
-                            aux["qs"], aux["gq"], ks, gk, causal=False, c=aux["c"], pv_mode=O.PV_F8_TWO_LEVEL, out_dtype=0,
-                            v_scale=aux["vs"], return_lse=True)
-        parts.append(util.f32(o_s, 0).astype(np.float64))
-        lses.append(lse_s.astype(np.float64))
-    lse = np.stack(lses)                                    # [S, B, H, L] log2 domain
+        o_s, lse_s = O.attn(np.ascontiguousarray(aux["q8"][:, :, r0:]), np.ascontiguousarray(aux["k8"][:, :, sl]),
+                            np.ascontiguousarray(aux["v8"][:, :, sl]), aux["qs"], np.ascontiguousarray(aux["gq"][r0:]), ks, gk,
+                            causal=causal, c=aux["c"], pv_mode=O.PV_F8_TWO_LEVEL, out_dtype=0, v_scale=aux["vs"], return_lse=True)
+        parts[s, :, :, r0:] = util.f32(o_s, 0)
+        lse[s, :, :, r0:] = lse_s
     m = lse.max(axis=0)
     w = np.exp2(lse - m)
-    o = (np.stack(parts) * w[..., None]).sum(axis=0) / w.sum(axis=0)[..., None]
+    o = (parts * w[..., None]).sum(axis=0) / w.sum(axis=0)[..., None]
     return o, m + np.log2(w.sum(axis=0))
 
 
-@pytest.mark.parametrize("case", [(1, 4, 4, 128, 4096, 128, 1, 4), (2, 4, 2, 200, 2048, 64, 0, 8), (1, 2, 1, 64, 1024, 128, 1, 2)],
-                         ids=["d128_bf16_s4", "gqa_d64_f16_s8", "gqa_d128_s2"])
+@pytest.mark.parametrize("case", [(1, 4, 4, 128, 4096, 128, 1, 4, False), (2, 4, 2, 200, 2048, 64, 0, 8, False), (1, 2, 1, 64, 1024, 128, 1, 2, False),
+                                  (1, 4, 2, 1024, 1024, 128, 1, 4, True), (2, 2, 2, 2048, 2048, 64, 0, 2, True), (1, 3, 3, 1000, 1024, 128, 1, 8, True)],
+                         ids=["d128_bf16_s4", "gqa_d64_f16_s8", "gqa_d128_s2", "causal_gqa_d128_s4", "causal_d64_s2", "causal_lq1000_s8"])
 def test_split_kv_vs_split_oracle_and_sdpa(oracle_mod, case):
     """Split-KV (chunks of the key range folded into the kv-head dimension + one log-sum-exp merge) against the same
     algorithm restated with the oracle (tolerance of the kernel tests), against the unsplit call and fp32 SDPA
-    (the FP8 accuracy bounds: a different split changes which running maximum each P is rounded against)."""
-    B, Hq, Hkv, Lq, Lk, D, dt, S = case
+    (the FP8 accuracy bounds: a different split changes which running maximum each P is rounded against).  Causal: the
+    mask runs in global key coordinates, chunks behind the diagonal contribute nothing."""
+    B, Hq, Hkv, Lq, Lk, D, dt, S, causal = case
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=500 + S, kbias=1.0)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=S)
-    o1, lse1 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=0)
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=S)
+    o1, lse1 = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, pv_accum_dtype="fp32+fp32", return_lse=True, split_kv=0)
     torch.cuda.synchronize()
     km = util.bits(sq.channel_mean(kd))
-    ref, lse_ref = _split_oracle(oracle_mod, q, k, v, dt, S, km)
+    ref, lse_ref = _split_oracle(oracle_mod, q, k, v, dt, S, km, causal)
     got = o.float().cpu().numpy()
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
-    REPORT[f"split_kv/{B}x{Hq}x{Lq}x{Lk}_d{D}_s{S}"] = dict(max_abs=err, max_o=scale)
+    REPORT[f"split_kv/{B}x{Hq}x{Lq}x{Lk}_d{D}_s{S}{'_causal' if causal else ''}"] = dict(max_abs=err, max_o=scale)
     assert np.isfinite(got).all() and err <= 2e-3 * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale
-    truth = util.sdpa_f32(qd, kd, vd, False).cpu().numpy()
+    truth = util.sdpa_f32(qd, kd, vd, causal).cpu().numpy()
     for res in (got, o1.float().cpu().numpy()):
         assert util.cos_sim(res, truth) >= 0.999
     assert (lse - lse1).abs().max().item() <= 2e-2           # same quantity through two summation orders (+ fp8 noise on l)
@@ -777,7 +784,9 @@ def test_split_kv_auto_plan_and_merge_kernel_edge_cases():
     from sageattention_amd import core, _cabi
     assert core._split_kv_plan(1, 32, 128, 32768, False, None) == 16          # 32 workgroups, 512 tiles -> 16 chunks of 32 tiles
     assert core._split_kv_plan(2, 32, 8192, 8192, False, None) == 0           # the grid already fills the chip
-    assert core._split_kv_plan(1, 32, 128, 32768, True, None) == 0            # causal calls are not split
+    assert core._split_kv_plan(1, 32, 128, 32768, True, None) == 0            # causal with Lq != Lk is not split
+    assert core._split_kv_plan(1, 8, 8192, 8192, True, None) == 0             # causal: only on request (measured slower)
+    assert core._split_kv_plan(1, 8, 8192, 8192, True, 4) == 4
     assert core._split_kv_plan(1, 8, 128, 32768 + 32, False, None) == 0       # ragged key range
     B, Hkv, group, S, L, D = 2, 2, 3, 4, 37, 64
     H = Hkv * group

@@ -81,7 +81,9 @@ def test_split_kv_planner():
     assert plan(1, 32, 128, 32768, False, None) == 16          # 32 workgroups, 512 key tiles -> 16 chunks of 32 tiles
     assert plan(1, 16, 1024, 16384, False, None) == 4          # 128 workgroups, 256 tiles: target 6 -> largest divisor of 256 below it
     assert plan(2, 32, 8192, 8192, False, None) == 0           # the grid already fills the chip
-    assert plan(1, 32, 128, 32768, True, None) == 0            # causal calls are not split
+    assert plan(1, 32, 128, 32768, True, None) == 0            # causal with Lq != Lk is not split
+    assert plan(1, 8, 8192, 8192, True, None) == 0             # causal: split only on request (measured slower, see core.py)
+    assert plan(1, 8, 8192, 8192, True, 4) == 4
     assert plan(1, 8, 128, 32768 + 32, False, None) == 0       # ragged key range
     assert plan(1, 8, 128, 2048, False, None) == 0             # short key range
     assert plan(1, 8, 128, 4096, False, 0) == 0                # switched off

@@ -12,6 +12,9 @@ SHAPES = [  # name, B, Hq, Hkv, Lq, Lk, D, causal
     ("cross-attn Lk=512 (video x text)", 2, 24, 24, 16384, 512, 128, False),
     ("cross-attn Lk=77", 2, 24, 24, 16384, 77, 128, False),
     ("B=1 H=8 N=8192 causal", 1, 8, 8, 8192, 8192, 128, True),
+    ("B=1 H=8 N=8192 causal, split off", 1, 8, 8, 8192, 8192, 128, True),
+    ("B=1 H=4 N=16384 causal", 1, 4, 4, 16384, 16384, 128, True),
+    ("B=1 H=4 N=16384 causal, split off", 1, 4, 4, 16384, 16384, 128, True),
     ("B=1 H=8 N=32768 causal", 1, 8, 8, 32768, 32768, 128, True),
     ("B=16 H=32 N=1024 causal", 16, 32, 32, 1024, 1024, 128, True),
     ("B=64 H=16 N=256 non-causal D=64", 64, 16, 16, 256, 256, 64, False),
