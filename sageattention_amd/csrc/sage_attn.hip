@@ -66,6 +66,9 @@
 #ifndef SAGE_PIPE16_ORDER   // 1: the PV MFMAs of two 32-channel tiles alternate (a third fragment set for a longer LDS lead measured no better)
 #define SAGE_PIPE16_ORDER 1
 #endif
+#ifndef SAGE_FEWNOPS    // experiment: s_nop 1 only in front of the first MFMA of each QK^T chain (FP8 pipelined loop)
+#define SAGE_FEWNOPS 0
+#endif
 #ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
 #define SAGE_ASMDMA 1   // M0 write per image, inst_offset for the second piece) instead of four builtins with 64-bit VGPR addresses
 #endif
@@ -987,9 +990,14 @@ sage_attn_kernel(const AttnParams p)
 #define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
 #define A_PKLO(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
 #define A_PKHI(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(a), "v"(b))
-#define A_PV(acc, av, bv, e8) asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
+#if SAGE_FEWNOPS
+#define SAGE_NOPX ""
+#else
+#define SAGE_NOPX "s_nop 1\n\t"
+#endif
+#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile(SAGE_NOPX "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
             if (it < n_steady) {
                 v16i sA[2], sB[2];
