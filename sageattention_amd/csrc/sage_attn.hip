@@ -262,6 +262,9 @@ sage_attn_kernel(const AttnParams p)
         n_iters = lim < n_iters ? lim : n_iters;
     }
 
+#ifdef SAGE_HACK_NOLOOP      // timing experiment only: no tiles at all -- what one workgroup costs outside its tile loop
+    n_iters = SAGE_HACK_NOLOOP;
+#endif
     // ---- Q fragments (B operand of S^T = K Q^T), resident in VGPRs ---------------------------
     v4i qf[C::KSTEPS];
     float qsc;
