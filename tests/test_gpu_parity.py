@@ -777,6 +777,10 @@ def test_split_kv_vs_split_oracle_and_sdpa(oracle_mod, case):
     assert (lse - lse1).abs().max().item() <= 2e-2           # same quantity through two summation orders (+ fp8 noise on l)
     with pytest.raises(ValueError):
         sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, split_kv=7)
+    # the same call on [B, L, H, D] tensors: identical bits (the INT8 K and the V image are stored head-major either way)
+    o_nhd = sa.sageattn_qk_int8_pv_fp8_cuda(qd.transpose(1, 2).contiguous(), kd.transpose(1, 2).contiguous(), vd.transpose(1, 2).contiguous(),
+                                            tensor_layout="NHD", is_causal=causal, pv_accum_dtype="fp32+fp32", split_kv=S)
+    assert torch.equal(o_nhd.transpose(1, 2), o)
 
 
 def test_split_kv_auto_plan_and_merge_kernel_edge_cases():
