@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 6
+#define SAGE_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -129,6 +129,30 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
                     int B, int H, int L, int D,
                     int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     float scale_max, int dtype, void *stream);
+
+/*
+ * The whole K / V pre-pass of the FP8-PV entry points as ONE launch that reads K and V once (2 B/elt in, 1 B/elt out):
+ *   K: km = k.mean(dim=seq) (core.py:280) -> k_mean [B,H,D] (input dtype), INT8 (k - km) + group scales as
+ *      sage_quant_qk_int8 writes them for is_key = 1, blk = warp = k_blk, qk_quant_gran per-block or per-thread;
+ *      k_mean == NULL: no smoothing (smooth_k = False)
+ *   V: v_image / v_scale / v_mean exactly as sage_prep_v_fp8 (v_mean != NULL => smooth_v)
+ * Either of k / v may be NULL to run one half.  Results are bit-identical to the sage_channel_mean +
+ * sage_quant_qk_int8 + sage_prep_v_fp8 sequence (6 launches, 4 B/elt read): same per-slab summation order.
+ *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
+ *   sync  sage_prepass_sync_words(B,H) uint32, ZERO before the first call; the kernel leaves it zero again, so calls issued
+ *         in stream order may share it -- concurrent calls (other streams) need their own
+ *   L     at most sage_prepass_max_seqlen() (32768): the slabs of a head wait for each other inside the launch; longer
+ *         sequences take the three-call sequence (SAGE_EINVAL here)
+ */
+SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D);
+SAGE_API int64_t sage_prepass_sync_words(int B, int H);
+SAGE_API int sage_prepass_max_seqlen(void);
+SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
+                    void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
+                    int B, int H, int L, int D,
+                    int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                    int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int dtype, void *stream);
 
 /* V pre-pass, FP16: (bf16 -> fp16) + transpose into the tile image.  Replaces `v.to(float16)`
  * (core.py:297-298,613) and, with v_mean != NULL ([B,H,D] fp32 to subtract), sub_mean_cuda

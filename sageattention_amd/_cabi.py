@@ -11,10 +11,11 @@ import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsage_gfx950.so")
+# SAGE_GFX950_LIB: load another build of the same library (A/B variants of tools/build_variants.sh)
+LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -35,6 +36,11 @@ SYMBOLS = {
     "sage_stats_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_channel_mean": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
     "sage_prep_v_fp8": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
+    "sage_prepass_ws_floats": (c_int64, [_I, _I, _I, _I]),
+    "sage_prepass_sync_words": (c_int64, [_I, _I]),
+    "sage_prepass_max_seqlen": (c_int, []),
+    "sage_prepass_kv": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _P]),
     "sage_prep_v_f16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
     "sage_prep_v_f16_varlen": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
     "sage_attn_qk_int8_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,

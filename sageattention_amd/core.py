@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _cabi, ops
 from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
-                    per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, sub_mean)
+                    per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
 
@@ -220,7 +220,8 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
     arch = get_gcn_arch(q.device) if q.is_cuda else "cpu"
     if arch.startswith(_SUPPORTED_ARCH_PREFIX):
         return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
-                                            return_lse=return_lse, pv_accum_dtype="fp32+fp32", split_kv=kwargs.get("split_kv"))
+                                            return_lse=return_lse, pv_accum_dtype="fp32+fp32", split_kv=kwargs.get("split_kv"),
+                                            fused_prepass=kwargs.get("fused_prepass", False))
     raise ValueError(f"Unsupported architecture: {arch} (sageattention_amd targets gfx950 / MI355X only)")
 
 
@@ -389,10 +390,17 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM).
         # (Running the V pre-pass on a side stream beside the K chain was measured and rejected: the two HBM-bound chains
         #  slow each other down and the cross-stream joins cost more than the launch gaps they hide, 956 -> 1130 us at C3.)
-        km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-        km_s = _squeeze_km(km, tensor_layout)
-        k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
-        v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+        if kwargs.get("fused_prepass", False) and prepass_fused_ok(k, tensor_layout) and k.shape == v.shape:
+            # opt-in: the whole K / V pre-pass as one launch that reads K and V once (sage_prepass_kv) -- same bits; measured
+            # slower than the six launches at the BASELINE shapes (177 vs 155 us at C3), hence opt-in
+            km_s, k_int8, k_scale, v_image, v_scale, vm = prepass_kv_fp8(k, v, tensor_layout, smooth_k=smooth_k, smooth_v=smooth_v)
+            km = None if km_s is None else km_s.unsqueeze(1 if tensor_layout == "NHD" else 2)
+            lse_correction = _lse_correction(q, km, tensor_layout) if (smooth_k and return_lse) else None
+        else:
+            km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+            km_s = _squeeze_km(km, tensor_layout)
+            k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
+            v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
         B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
         n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
         if n_split:

@@ -485,11 +485,9 @@ sage_attn_kernel(const AttnParams p)
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             int q8[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton(x[ks][j], sc, y);
+            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton_nz(x[ks][j], sc, y);
 #pragma unroll
-            for (int w = 0; w < 4; w++)
-                qf[ks][w] = (int)((unsigned)(q8[4 * w] & 0xff) | ((unsigned)(q8[4 * w + 1] & 0xff) << 8) |
-                                  ((unsigned)(q8[4 * w + 2] & 0xff) << 16) | ((unsigned)(q8[4 * w + 3] & 0xff) << 24));
+            for (int w = 0; w < 4; w++) qf[ks][w] = (int)pack_int8x4(q8[4 * w], q8[4 * w + 1], q8[4 * w + 2], q8[4 * w + 3]);
         }
     }
 

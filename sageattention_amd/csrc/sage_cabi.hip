@@ -233,6 +233,59 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
                          scale_max, dtype, 1, stream);
 }
 
+SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D)
+{
+    const int64_t nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+    return 2 * (int64_t)B * H * nslab * 3 * D;
+}
+
+SAGE_API int64_t sage_prepass_sync_words(int B, int H) { return 2 * (int64_t)B * H * sage::kPrepassSyncStride; }
+
+SAGE_API int sage_prepass_max_seqlen(void) { return sage::kPrepassMaxSlabs * sage::kStatsSlab; }
+
+SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
+                    void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
+                    int B, int H, int L, int D,
+                    int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                    int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int dtype, void *stream)
+{
+    SAGE_REQUIRE(k || v, "nothing to do: both k and v are null");
+    SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its (zeroed) sync buffer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
+    SAGE_REQUIRE(B <= 32767, "batch too large for one launch (%d)", B);
+    SAGE_REQUIRE(L <= sage_prepass_max_seqlen(), "sequence too long for the in-launch head barrier (%d > %d): use the "
+                 "sage_channel_mean / sage_quant_qk_int8 / sage_prep_v_fp8 sequence", L, sage_prepass_max_seqlen());
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    sage::PrepassParams p{};
+    p.parts = (k ? 1 : 0) | (v ? 2 : 0);
+    if (k) {
+        SAGE_REQUIRE(k_int8 && k_scale, "K part needs k_int8 and k_scale");
+        SAGE_REQUIRE(aligned16(k) && aligned16(k_int8), "k / k_int8 must be 16-byte aligned");
+        SAGE_REQUIRE(k_sl % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0, "input strides must be multiples of 8 elements");
+        SAGE_REQUIRE(ko_sl % 16 == 0 && ko_sh % 16 == 0 && ko_sb % 16 == 0, "int8 output strides must be multiples of 16");
+        SAGE_REQUIRE(k_blk == 64 || k_blk == 128, "k_blk must be 64 or 128 (got %d)", k_blk);
+        SAGE_REQUIRE(k_style >= 0 && k_style <= 2, "bad style %d", k_style);
+        if (qk_quant_gran == SAGE_GRAN_PER_BLOCK) p.k_gran = sage::GR_BLOCK;
+        else if (qk_quant_gran == SAGE_GRAN_PER_THREAD) p.k_gran = sage::GR_THREAD_K;
+        else return fail(SAGE_EINVAL, "bad k granularity %d (per-block or per-thread)", qk_quant_gran);
+    }
+    if (v) {
+        SAGE_REQUIRE(v_image && v_scale, "V part needs v_image and v_scale");
+        SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
+        SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "input strides must be multiples of 8 elements");
+        SAGE_REQUIRE(scale_max > 0.0f, "scale_max must be positive");
+    }
+    p.k = k; p.v = v; p.k_mean = k_mean; p.k_out = k_int8; p.k_scale = k_scale;
+    p.v_image = v_image; p.v_scale = v_scale; p.v_mean = v_mean; p.ws = ws; p.sync = sync;
+    p.B = B; p.H = H; p.L = L; p.D = D; p.nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+    p.ko_sb = ko_sb; p.ko_sh = ko_sh; p.ko_sl = ko_sl;
+    p.k_blk = k_blk; p.k_warp = k_blk; p.k_style = k_style; p.dtype = dtype; p.scale_max = scale_max;
+    return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv launch");
+}
+
 SAGE_API int sage_prep_v_f16(const void *v, void *v_image, const float *v_mean, int B, int H, int L, int D,
                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int dtype, void *stream)
 {

@@ -71,7 +71,10 @@ struct QuantParams {
 hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream);
 
 // ---- per-channel statistics over the sequence (K mean, V amax / mean) -----------------------------
-constexpr int kStatsSlab = 512;   // tokens per stage-1 workgroup
+#ifndef SAGE_STATS_SLAB
+#define SAGE_STATS_SLAB 512
+#endif
+constexpr int kStatsSlab = SAGE_STATS_SLAB;   // tokens per stage-1 workgroup
 struct StatsParams {
     const void *x;            // fp16 / bf16 [.., L, D] with strides
     float *ws;                // [B,H,nslab,3,D] partial (max, min, sum)
@@ -100,6 +103,34 @@ struct PrepVParams {
     float scale_max;
 };
 hipError_t launch_prep_v(const PrepVParams &p, hipStream_t stream);
+
+// ---- fused K / V pre-pass: one launch, one read of K and V (sage_prepass.hip) -----------------------------------------
+constexpr int kPrepassMaxSlabs = 32768 / kStatsSlab;   // slabs of one head that wait for each other inside the launch (L <= 32768)
+constexpr int kPrepassSyncStride = 32;  // uint32 words per (part, head): arrival + departure counter on their own 128-B line
+struct PrepassParams {
+    const void *k;            // fp16 / bf16 [.., L, D] with strides (parts & 1)
+    const void *v;            // same shape (parts & 2)
+    void *k_mean;             // nullable [B,H,D] out, input dtype; non-null = smooth_k (subtract it before quantising)
+    int8_t *k_out;            // INT8 K, strides ko_*
+    float *k_scale;           // [B,H,ceil(L/k_blk)*groups]
+    void *v_image;            // fp8 tile image [B,H,ceil(L/64),D,64]
+    float *v_scale;           // [B,H,D] out
+    float *v_mean;            // nullable [B,H,D] out; non-null = smooth_v
+    float *ws;                // [2,B,H,nslab,3,D] slab partials
+    unsigned *sync;           // [2,B,H,kPrepassSyncStride] arrival / departure counters, zero on entry, zero again on exit
+    int B, H, L, D, nslab;
+    long k_sb, k_sh, k_sl;
+    long v_sb, v_sh, v_sl;
+    long ko_sb, ko_sh, ko_sl;
+    int parts;                // 1: K only, 2: V only, 3: both
+    int k_blk;                // keys per scale block: 64 / 128
+    int k_warp;               // == k_blk (one thread-group map per block)
+    int k_gran;               // GR_BLOCK / GR_THREAD_K
+    int k_style;              // QS_*
+    int dtype;
+    float scale_max;          // 448 for e4m3
+};
+hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t stream);
 
 // ---- LSE merge of partial attention states (sequence-parallel callers) -----------------------------
 struct MergeParams {

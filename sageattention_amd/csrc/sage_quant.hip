@@ -16,14 +16,6 @@
 
 namespace sage {
 
-__device__ __forceinline__ int group_of_row(int r, int gran, int warp)
-{
-    if (gran == GR_BLOCK) return 0;
-    if (gran == GR_WARP) return r / warp;
-    if (gran == GR_THREAD_Q) return (r / warp) * 8 + (r & 7);     // quant_per_thread.py:27-37
-    return (r / warp) * 4 + ((r & 7) >> 1);                       // quant_per_thread.py:75-83
-}
-
 template <int D, int BLK, int DT>
 __global__ void __launch_bounds__(256)
 quant_int8_kernel(const QuantParams p)
@@ -124,14 +116,17 @@ quant_int8_kernel(const QuantParams p)
             // the +-0.5 / truncate that follows makes a 1-ulp error visible in the int8): sage_quant_math.h
             const float sc = quant_scale(am, p.style);
             const float y = quant_recip(sc);
+            if (p.style == QS_TRITON_THREAD) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) q[j] = quant_round_triton(v[i][j], sc, y);
+                for (int j = 0; j < 16; j++) q[j] = quant_round_triton_nz(v[i][j], sc, y);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) q[j] = quant_round_triton(v[i][j], sc, y);
+            }
         }
         v4u pk;
 #pragma unroll
-        for (int w = 0; w < 4; w++)
-            pk[w] = (unsigned)(q[4 * w] & 0xff) | ((unsigned)(q[4 * w + 1] & 0xff) << 8) |
-                    ((unsigned)(q[4 * w + 2] & 0xff) << 16) | ((unsigned)(q[4 * w + 3] & 0xff) << 24);
+        for (int w = 0; w < 4; w++) pk[w] = pack_int8x4(q[4 * w], q[4 * w + 1], q[4 * w + 2], q[4 * w + 3]);
         *reinterpret_cast<v4u *>(p.out + ooff + (long)row * p.o_sl + col) = pk;
     }
 }

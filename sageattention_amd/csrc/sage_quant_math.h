@@ -6,6 +6,15 @@
 
 namespace sage {
 
+// row (inside its block) -> scale group
+__device__ __forceinline__ int group_of_row(int r, int gran, int warp)
+{
+    if (gran == GR_BLOCK) return 0;
+    if (gran == GR_WARP) return r / warp;
+    if (gran == GR_THREAD_Q) return (r / warp) * 8 + (r & 7);     // quant_per_thread.py:27-37
+    return (r / warp) * 4 + ((r & 7) >> 1);                       // quant_per_thread.py:75-83
+}
+
 // scale of a quantisation group from its abs-max (QS_CUDA floors the abs-max at 1e-7 before calling, fused.cu:147)
 __device__ __forceinline__ float quant_scale(float amax, int style)
 {
@@ -30,6 +39,25 @@ __device__ __forceinline__ int quant_round_triton(float x, float sc, float y)
     int qi = (int)t;                                             // truncation toward zero
     qi = qi > 127 ? 127 : (qi < -128 ? -128 : qi);
     return (sc == 0.0f) ? 0 : qi;
+}
+
+// The same quotient when the scale cannot be zero or subnormal (QS_TRITON_THREAD: amax / 127 + 1e-7): |x / sc| < 127.001, so
+// the clamp and the zero-scale select of quant_round_triton never act and are left out; +-0.5 is one v_bfi (copysign).
+__device__ __forceinline__ int quant_round_triton_nz(float x, float sc, float y)
+{
+    float t = x * y;
+    t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
+    t = __builtin_fmaf(__builtin_fmaf(-sc, t, x), y, t);
+    t += __builtin_copysignf(0.5f, t);
+    return (int)t;
+}
+
+// four INT8 lanes of one dword from four integers in [-128, 127]: three v_perm_b32 / v_or
+__device__ __forceinline__ unsigned pack_int8x4(int q0, int q1, int q2, int q3)
+{
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);
+    return lo | hi;
 }
 
 // CUDA convention: x * (127 / amax), round to nearest even, saturate (cvt.rni.sat.s8.f32, fused.cu:164-172)

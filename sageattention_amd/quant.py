@@ -219,6 +219,71 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     return v_image, v_scale, vm
 
 
+_sync_cache: dict = {}
+
+
+def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
+    """Zeroed arrival counters of the fused pre-pass.  The kernel leaves them zero again, so one buffer per
+    (device, stream) serves every call issued in stream order; while a HIP graph is being captured the buffer is
+    private to the capture (its zero fill becomes a node of the graph)."""
+    words = int(_cabi.load().sage_prepass_sync_words(B, H))
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((words,), dtype=torch.int32, device=device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
+    buf = _sync_cache.get(key)
+    if buf is None or buf.numel() < words:
+        buf = torch.zeros((max(words, 4096),), dtype=torch.int32, device=device)
+        _sync_cache[key] = buf
+    return buf
+
+
+def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
+    """Whether the one-launch pre-pass covers this K / V length (the slabs of a head wait for each other in the launch)."""
+    return _dims(k, tensor_layout)[2] <= int(_cabi.load().sage_prepass_max_seqlen())
+
+
+@_eager
+def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: str = "HND", smooth_k: bool = True,
+                   smooth_v: bool = False, BLKK: int = 64, qk_quant_gran: str = "per_thread", scale_max: float = 448.0):
+    """K and V pre-pass of the FP8-PV entry points in ONE launch that reads K and V once: the bits of
+    ``channel_mean`` + ``per_thread_int8`` / ``per_warp_int8`` (K side) + ``per_channel_fp8``.
+    Returns ``(km [B,H,D] | None, k_int8, k_scale, v_image, v_scale, vm)``; ``v=None`` runs the K half only
+    (``v_image, v_scale, vm`` are None).  ``qk_quant_gran`` "per_thread" gives 4 k scales per BLKK keys with the
+    Triton-per-thread rounding, "per_warp" / "per_block" one scale per BLKK keys with the CUDA rounding
+    (quant.py:105-180) -- the K conventions of the reference's CUDA entry points."""
+    k = _aligned(k, 8)
+    B, H, L, D, k_sb, k_sh, k_sl = _dims(k, tensor_layout)
+    dev = k.device
+    k_int8 = torch.empty((B, H, L, D), dtype=torch.int8, device=dev)          # head-major in memory (see _quant)
+    if tensor_layout == "NHD":
+        k_int8 = k_int8.permute(0, 2, 1, 3)
+    _, _, _, _, ob, oh, ol = _dims(k_int8, tensor_layout)
+    if qk_quant_gran == "per_thread":
+        gran, style, slots = _cabi.GRAN_PER_THREAD, _cabi.QSTYLE_TRITON_THREAD, 4
+    else:
+        gran, style, slots = _cabi.GRAN_PER_BLOCK, _cabi.QSTYLE_CUDA, 1
+    k_scale = torch.empty((B, H, ((L + BLKK - 1) // BLKK) * slots), dtype=torch.float32, device=dev)
+    km = torch.empty((B, H, D), dtype=k.dtype, device=dev) if smooth_k else None
+    v_image = v_scale = vm = None
+    v_sb = v_sh = v_sl = 0
+    if v is not None:
+        v = _aligned(v, 8)
+        assert _dims(v, tensor_layout)[:4] == (B, H, L, D) and v.dtype == k.dtype, "k and v must have one shape and dtype"
+        _, _, _, _, v_sb, v_sh, v_sl = _dims(v, tensor_layout)
+        v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.uint8, device=dev)
+        v_scale = torch.empty((B, H, D), dtype=torch.float32, device=dev)
+        vm = torch.empty((B, H, D), dtype=torch.float32, device=dev) if smooth_v else None
+    lib = _cabi.load()
+    ws = torch.empty((int(lib.sage_prepass_ws_floats(B, H, L, D)),), dtype=torch.float32, device=dev)
+    sync = _prepass_sync(B, H, dev)
+    rc = lib.sage_prepass_kv(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(v_scale), _p(vm), _p(ws), _p(sync),
+                             B, H, L, D, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, ob, oh, ol,
+                             BLKK, gran, style, float(scale_max), _dtype_code(k), _stream(k))
+    _cabi.check(rc, "sage_prepass_kv")
+    return km, k_int8, k_scale, v_image, v_scale, vm
+
+
 @_eager
 def prep_v_fp16(v: torch.Tensor, tensor_layout: str = "HND", vm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """FP16-PV paths: ``v.to(float16)`` (core.py:297-298,613) -- or ``(v - vm).to(float16)`` when a

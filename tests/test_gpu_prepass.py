@@ -1,0 +1,133 @@
+"""The one-launch K / V pre-pass (sage_prepass_kv) against the kernel sequence it replaces: every output bit-equal.
+
+The sequence (sage_channel_mean + sage_quant_qk_int8 + sage_prep_v_fp8) is itself pinned to the oracle by
+tests/test_gpu_parity.py, so bit-equality here carries that parity over."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sageattention_amd import _cabi, quant
+
+
+def _mk(B, H, L, D, dtype, layout, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    shape = (B, H, L, D) if layout == "HND" else (B, L, H, D)
+    k = torch.randn(shape, device="cuda", dtype=torch.float32, generator=g)
+    v = torch.randn(shape, device="cuda", dtype=torch.float32, generator=g)
+    chan = torch.linspace(-2.0, 3.0, D, device="cuda")
+    return (k * 1.5 + chan).to(dtype), (v * (1.0 + chan.abs()) + 0.5 * chan).to(dtype)
+
+
+def _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran):
+    km = quant.channel_mean(k, layout) if smooth_k else None
+    if gran == "per_thread":
+        k8, ks = quant._quant(k, km, blkk, blkk, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, layout, 4)
+    else:
+        k8, ks = quant._quant(k, km, blkk, blkk, _cabi.GRAN_PER_BLOCK, True, _cabi.QSTYLE_CUDA, 1.0, layout, 1)
+    vi, vs, vm = quant.per_channel_fp8(v, tensor_layout=layout, scale_max=448.0, smooth_v=smooth_v)
+    return km, k8, ks, vi, vs, vm
+
+
+def _same(a, b, what):
+    if a is None or b is None:
+        assert a is None and b is None, what
+        return
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    if a.dtype in (torch.float16, torch.bfloat16):
+        a, b = a.view(torch.int16), b.view(torch.int16)
+    elif a.dtype == torch.float32:
+        a, b = a.view(torch.int32), b.view(torch.int32)
+    assert torch.equal(a, b), f"{what}: {(a != b).sum().item()} of {a.numel()} differ"
+
+
+CASES = [  # B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran
+    (2, 4, 1024, 128, torch.bfloat16, "HND", True, False, 64, "per_thread"),
+    (1, 3, 4096, 128, torch.float16, "HND", True, True, 64, "per_thread"),
+    (2, 2, 1000, 128, torch.bfloat16, "NHD", True, True, 64, "per_thread"),       # ragged tail, L % 16 != 0
+    (1, 2, 77, 128, torch.float16, "HND", True, True, 64, "per_warp"),            # one partial slab
+    (2, 3, 2048 + 513, 64, torch.bfloat16, "HND", True, False, 64, "per_thread"),
+    (1, 5, 1536, 64, torch.float16, "NHD", True, True, 64, "per_warp"),
+    (1, 2, 3000, 128, torch.bfloat16, "HND", True, False, 128, "per_thread"),     # the sm90 entry point's 128-key groups
+    (2, 2, 640, 64, torch.float16, "HND", True, False, 128, "per_warp"),
+    (1, 2, 2048, 128, torch.bfloat16, "HND", False, False, 64, "per_thread"),     # smooth_k off: no statistics for K
+    (1, 1, 32768, 128, torch.bfloat16, "HND", True, True, 64, "per_thread"),      # 64 slabs: the longest head
+    (1, 2, 1, 64, torch.float16, "HND", True, True, 64, "per_thread"),
+]
+
+
+@pytest.mark.parametrize("B,H,L,D,dtype,layout,smooth_k,smooth_v,blkk,gran", CASES)
+def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran):
+    k, v = _mk(B, H, L, D, dtype, layout, 7 * L + D)
+    ref = _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran)
+    for rep in range(3):                   # the sync counters must come back to zero after every call
+        got = quant.prepass_kv_fp8(k, v, layout, smooth_k=smooth_k, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran)
+        for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+            _same(a, b, f"{name} (call {rep})")
+    key = (torch.cuda.current_device(), torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    assert int(quant._sync_cache[key].abs().sum().item()) == 0
+
+
+def test_k_half_only_and_side_stream():
+    k, v = _mk(2, 4, 2048, 128, torch.bfloat16, "HND", 3)
+    ref = _sequence(k, v, "HND", True, False, 64, "per_thread")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = quant.prepass_kv_fp8(k, None, "HND", smooth_k=True)
+    got_main = quant.prepass_kv_fp8(k, v, "HND", smooth_k=True)       # concurrently, on its own sync buffer
+    torch.cuda.current_stream().wait_stream(side)
+    for a, b, name in zip(got[:3], ref[:3], ("km", "k_int8", "k_scale")):
+        _same(a, b, name + " (K half, side stream)")
+    assert got[3] is None and got[4] is None and got[5] is None
+    for a, b, name in zip(got_main, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+        _same(a, b, name)
+
+
+def test_many_small_heads_and_full_chip():
+    # more workgroups than the chip holds at once (2 * 64 * 16 * 2 = 4096), heads of 16 slabs each
+    k, v = _mk(2, 64, 8192, 128, torch.bfloat16, "HND", 11)
+    ref = _sequence(k, v, "HND", True, False, 64, "per_thread")
+    got = quant.prepass_kv_fp8(k, v, "HND", smooth_k=True)
+    for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+        _same(a, b, name)
+
+
+def test_too_long_is_refused():
+    k = torch.zeros(1, 1, 32768 + 512, 64, device="cuda", dtype=torch.float16)
+    assert not quant.prepass_fused_ok(k)
+    with pytest.raises(ValueError, match="too long"):
+        quant.prepass_kv_fp8(k, k)
+
+
+def test_graph_capture_replays():
+    k, v = _mk(1, 4, 4096, 128, torch.bfloat16, "HND", 5)
+    ref = _sequence(k, v, "HND", True, True, 64, "per_thread")
+    quant.prepass_kv_fp8(k, v, "HND", smooth_k=True, smooth_v=True)     # warm the allocator outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = quant.prepass_kv_fp8(k, v, "HND", smooth_k=True, smooth_v=True)
+    for _ in range(3):
+        for t in got:
+            if t is not None:
+                t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+            _same(a, b, name + " (graph replay)")
+
+
+@pytest.mark.parametrize("layout,causal", [("HND", True), ("NHD", False)])
+def test_sageattn_with_fused_prepass_is_bit_equal(layout, causal):
+    import sageattention_amd as sa
+    g = torch.Generator(device="cuda").manual_seed(21)
+    shape = (2, 4, 1500, 128) if layout == "HND" else (2, 1500, 4, 128)
+    q, k, v = (torch.randn(shape, device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(3))
+    k = k + 0.75
+    kw = dict(tensor_layout=layout, is_causal=causal, return_lse=True)
+    call = lambda **e: sa.sageattn(q, k, v, **kw, **e)
+    o0, l0 = call()
+    o1, l1 = call(fused_prepass=True)
+    _same(o1, o0, "o")
+    _same(l1, l0, "lse")

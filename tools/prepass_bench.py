@@ -38,6 +38,16 @@ cases = [
     ("per_channel_fp8 (v: stats + image)", lambda: sq.per_channel_fp8(v), (2 + 2 + 1) * elts),
     ("prep_v_fp16 (v image)", lambda: sq.prep_v_fp16(v), 4 * elts),
 ]
+def sequence():
+    m = sq.channel_mean(k)
+    sq._quant(k, m, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, "HND", 4)
+    sq.per_channel_fp8(v)
+if sq.prepass_fused_ok(k):
+    cases += [
+        ("K+V pre-pass, 6-launch sequence", sequence, 2 * 3 * elts),
+        ("K+V pre-pass, one launch (sage_prepass_kv)", lambda: sq.prepass_kv_fp8(k, v), 2 * 3 * elts),
+        ("K half, one launch", lambda: sq.prepass_kv_fp8(k, None), 3 * elts),
+    ]
 for name, fn, nbytes in cases:
     dt = t(fn)
-    print(f"{name:40s} {dt*1e6:8.1f} us  {nbytes/dt/1e9:8.0f} GB/s")
+    print(f"{name:46s} {dt*1e6:8.1f} us  {nbytes/dt/1e9:8.0f} GB/s")
