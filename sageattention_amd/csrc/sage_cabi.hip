@@ -254,7 +254,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
     SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its (zeroed) sync buffer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
     SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
-    SAGE_REQUIRE(B <= 32767, "batch too large for one launch (%d)", B);
+    SAGE_REQUIRE(B <= 32767 && H <= 65535, "batch / head count too large for one launch (%d, %d)", B, H);
     SAGE_REQUIRE(L <= sage_prepass_max_seqlen(), "sequence too long for the in-launch head barrier (%d > %d): use the "
                  "sage_channel_mean / sage_quant_qk_int8 / sage_prep_v_fp8 sequence", L, sage_prepass_max_seqlen());
     SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
@@ -266,7 +266,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(k_sl % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0, "input strides must be multiples of 8 elements");
         SAGE_REQUIRE(ko_sl % 16 == 0 && ko_sh % 16 == 0 && ko_sb % 16 == 0, "int8 output strides must be multiples of 16");
         SAGE_REQUIRE(k_blk == 64 || k_blk == 128, "k_blk must be 64 or 128 (got %d)", k_blk);
-        SAGE_REQUIRE(k_style >= 0 && k_style <= 2, "bad style %d", k_style);
+        SAGE_REQUIRE(k_style == sage::QS_CUDA || k_style == sage::QS_TRITON_THREAD, "k_style must be the CUDA (1) or the per-thread Triton (2) convention (got %d)", k_style);
         if (qk_quant_gran == SAGE_GRAN_PER_BLOCK) p.k_gran = sage::GR_BLOCK;
         else if (qk_quant_gran == SAGE_GRAN_PER_THREAD) p.k_gran = sage::GR_THREAD_K;
         else return fail(SAGE_EINVAL, "bad k granularity %d (per-block or per-thread)", qk_quant_gran);

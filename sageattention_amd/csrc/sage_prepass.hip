@@ -24,6 +24,9 @@
 #include "sage_quant_math.h"
 #include <type_traits>
 
+#ifndef SAGE_PP_TRACE
+#define SAGE_PP_TRACE 0    // experiment: thread 0 of every workgroup appends 100 MHz time stamps behind the used part of ws
+#endif
 #ifndef SAGE_PP_ABL
 #define SAGE_PP_ABL 0      // experiment bits (wrong results): 1 no wait, 2 no quantise step, 4 no slab statistics
 #endif
@@ -50,34 +53,44 @@ template <int DT> __device__ __forceinline__ void round_pair_to_dtype(float &a, 
 
 constexpr int kPrepassThreads = 512;
 
-template <int D, int DT>
-__global__ void __launch_bounds__(kPrepassThreads, 4)
-prepass_kv_kernel(const PrepassParams p)
+template <int D>
+struct PrepassLds {
+    static constexpr int TPR = D / 4, RPI = kPrepassThreads / TPR, LDT = D + 8;
+    float red[3][RPI][D];
+    __attribute__((aligned(16))) uint16_t tile[2][BLKK * LDT];
+    float ch_mean[D], ch_recp[D];
+    uint16_t kmean[D];
+    unsigned gmax[8][8];
+    float gsc[8][8], gy[8][8];
+};
+
+// The K half and the V half are two instantiations of this body under one workgroup-uniform branch of the kernel.  Written as
+// one body with `is_v` selects they needed > 128 VGPRs and spilled (every reload is a memory round trip behind
+// `s_waitcnt vmcnt(0)`: the passes ran 2.5x slower); as two disjoint regions they take 115 / 127 and nothing spills.
+template <int D, int DT, bool IS_V>
+__device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<D> &lds, const int b)
 {
+
     // 512 threads, 4 channels (8 B) per thread and row: a row is D / 4 threads wide, the workgroup passes over RPI rows at
     // a time and thread (r0, c4) owns rows r0 + RPI * i -- the row -> thread map of stats_partial_kernel (RPI = 16 at D = 128,
     // 32 at D = 64), so the per-channel sums associate the same way.  64 data VGPRs per thread (D = 128) leave room for
-    // 4 waves / SIMD: two slabs per CU as with 256 threads x 8 channels, but twice the waves to hide the latency of the
-    // compute steps (which, not HBM, bounded the 256-thread version: 194 us against 154 us for the six launches at C3).
+    // 4 waves / SIMD: two slabs per CU, sixteen waves to hide the latency of the compute steps.
+    // Every loop over the rows is unrolled with static register indices; the code stays at ~5k instructions because a
+    // thread has only 4 channels, the arithmetic is packed (v_pk_*_f32) and the rounding style is a template argument.
+    // (History, C3 shape, six-launch sequence = 154 us: 8 channels x 256 threads fully unrolled with run-time style
+    //  branches = 20k instructions, instruction-fetch bound, 437 us; rolled loops over s_set_gpr_idx-indexed register
+    //  tuples = 177 us, ~100 cycles per element in the passes -- profiles/r2_run_r3e_trace_c3.txt.)
     constexpr int NT = kPrepassThreads;
     constexpr int TPR = D / 4;                  // threads per row
     constexpr int RPI = NT / TPR;               // rows per pass of the workgroup
     constexpr int NR = kStatsSlab / RPI;        // rows per thread: 32 (D = 128) / 16 (D = 64)
     constexpr int LDT = D + 8;
-    // The slab lives in two register tuples (dword c of row i = rw[c][i]) that the loops below index with a wave-uniform
-    // counter (s_set_gpr_idx): rolled loops keep the kernel at ~2k instructions.  Fully unrolled it was 20k instructions
-    // (120 KB) of straight-line code that every wave fetched exactly once -- instruction fetch set its speed.
-    typedef unsigned rows_t __attribute__((ext_vector_type(NR)));
-    __shared__ float red[3][RPI][D];
-    __shared__ __attribute__((aligned(16))) uint16_t tile[2][BLKK * LDT];
-    __shared__ float ch_mean[D], ch_recp[D];
-    __shared__ uint16_t kmean[D];
-    __shared__ unsigned gmax[8][8];
+    auto &red = lds.red; auto &tile = lds.tile; auto &ch_mean = lds.ch_mean; auto &ch_recp = lds.ch_recp;
+    auto &kmean = lds.kmean; auto &gmax = lds.gmax; auto &gsc = lds.gsc; auto &gy = lds.gy;
+    constexpr int is_v = IS_V ? 1 : 0;
 
     const int tid = threadIdx.x;
     const int slab = blockIdx.x, h = blockIdx.y;
-    const int is_v = (p.parts == 3) ? (int)(blockIdx.z & 1) : (p.parts == 2);
-    const int b = (p.parts == 3) ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
     const int L = p.L;
     const long bh = (long)b * p.H + h;
     const uint16_t *x = is_v ? reinterpret_cast<const uint16_t *>(p.v) + (long)b * p.v_sb + (long)h * p.v_sh
@@ -86,16 +99,43 @@ prepass_kv_kernel(const PrepassParams p)
     const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
     const int row0 = slab * kStatsSlab;
     const int end = min(L, row0 + kStatsSlab);
+    const bool full = end - row0 == kStatsSlab;                 // workgroup-uniform: every row of the slab exists
     const int my_rows = (end - row0 - r0 + RPI - 1) / RPI;      // rows i < my_rows of this thread exist (may be <= 0)
+#if SAGE_PP_TRACE
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(p.ws + 2L * p.B * p.H * p.nslab * 3 * D) +
+                                8L * (blockIdx.x + gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z));
+    int tslot = 0;
+#define SAGE_STAMP() do { if (tid == 0) trace[tslot] = wall_clock64(); tslot++; } while (0)
+    SAGE_STAMP();
+#else
+#define SAGE_STAMP() do { } while (0)
+#endif
 
     // ---- the slab, one read -------------------------------------------------------------------------------------
-    rows_t rw[2];
+    unsigned rw[NR][2];
+    {
+        // buffer loads: rows past the end of the head read as zero (range check of the byte offset against num_records), so
+        // the 32 loads need no branch -- a full / partial branch here costs a second copy of the slab in registers
+        const unsigned head_bytes = (unsigned)(((long)(L - 1) * x_sl + D) * 2);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(x), 0, head_bytes, 0x00020000);
+        const unsigned toff = (unsigned)((row0 + r0) * (int)x_sl + c4) * 2u;
+        const unsigned step = (unsigned)(RPI * (int)x_sl) * 2u;
+        unsigned voff = toff;                  // one running offset register (not 32 precomputed ones)
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-        v2u t = {0u, 0u};
-        if (i < my_rows) t = *reinterpret_cast<const v2u *>(x + (long)(row0 + r0 + i * RPI) * x_sl + c4);
-        rw[0][i] = t[0]; rw[1][i] = t[1];
+        for (int i = 0; i < NR; i++) {
+            const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+            rw[i][0] = t[0]; rw[i][1] = t[1];
+            voff += step;
+            asm volatile("" : "+v"(voff));
+        }
     }
+#if SAGE_PP_TRACE
+    { unsigned acc = 0;
+#pragma unroll
+      for (int i = 0; i < NR; i++) acc += rw[i][0] ^ rw[i][1];
+      if (acc == 0x12345u) p.ws[0] = 1.0f; }      // the loads have landed
+    SAGE_STAMP();                                  // 1: slab loaded
+#endif
 
     const bool need_stats = is_v || p.k_mean != nullptr;
     if (need_stats) {
@@ -103,22 +143,22 @@ prepass_kv_kernel(const PrepassParams p)
         float mx[4], mn[4], sm[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; sm[j] = 0.0f; }
+        // rows past the end read as zeros: exact for the sums; selects keep them out of max / min.  (One loop for whole and
+        // partial slabs: a specialised copy for whole slabs saves the selects but tips the register allocation into spilling.)
         if (!(SAGE_PP_ABL & 4)) {
-#pragma unroll 1
-            for (int g = 0; g < NR; g += 4) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int i = g + m;
-                    if (i < my_rows) {
+            for (int i = 0; i < NR; i++) {
+                const bool valid = full || i < my_rows;
 #pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            const unsigned w = rw[c][i];
-                            const float lo = ld16<DT>((uint16_t)(w & 0xffffu)), hi = ld16<DT>((uint16_t)(w >> 16));
-                            mx[2 * c] = fmaxf(mx[2 * c], lo);         mn[2 * c] = fminf(mn[2 * c], lo);         sm[2 * c] += lo;
-                            mx[2 * c + 1] = fmaxf(mx[2 * c + 1], hi); mn[2 * c + 1] = fminf(mn[2 * c + 1], hi); sm[2 * c + 1] += hi;
-                        }
-                    }
+                for (int c = 0; c < 2; c++) {
+                    const unsigned w = rw[i][c];
+                    const float lo = ld16<DT>((uint16_t)(w & 0xffffu)), hi = ld16<DT>((uint16_t)(w >> 16));
+                    mx[2 * c] = fmaxf(mx[2 * c], valid ? lo : -INFINITY);         mn[2 * c] = fminf(mn[2 * c], valid ? lo : INFINITY);
+                    mx[2 * c + 1] = fmaxf(mx[2 * c + 1], valid ? hi : -INFINITY); mn[2 * c + 1] = fminf(mn[2 * c + 1], valid ? hi : INFINITY);
+                    sm[2 * c] += lo;
+                    sm[2 * c + 1] += hi;
                 }
+                asm volatile("" ::: "memory");
             }
         }
 #pragma unroll
@@ -134,6 +174,7 @@ prepass_kv_kernel(const PrepassParams p)
             __hip_atomic_store(mine + D + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(mine + 2 * D + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        SAGE_STAMP();                              // 2: slab statistics published
         // ---- 2. per-head barrier over the slabs, then the reduction in slab order (as stats_final_kernel) -------------
         unsigned *cnt = p.sync + ((long)is_v * p.B * p.H + bh) * kPrepassSyncStride;   // one 128-B line per head
         if (p.nslab > 1 && !(SAGE_PP_ABL & 1)) {
@@ -151,6 +192,7 @@ prepass_kv_kernel(const PrepassParams p)
             }
             __syncthreads();
         }
+        SAGE_STAMP();                              // 3: every slab of the head has arrived
         if (tid < D) {
             // slabs in index order; eight slabs' loads are in flight together (one round trip to the coherence point per batch,
             // not one per slab: with the loads issued one by one this loop alone cost ~2 us x nslab per workgroup)
@@ -169,7 +211,7 @@ prepass_kv_kernel(const PrepassParams p)
                     if (i0 + u < p.nslab) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); s += vs[u]; }
                 }
             }
-            if (!is_v) {
+            if constexpr (!IS_V) {
                 const uint16_t m = st16<DT>(s / (float)L);           // k.mean(dim=seq) in the input dtype, one rounding
                 kmean[tid] = m;
                 if (slab == 0) reinterpret_cast<uint16_t *>(p.k_mean)[bh * D + tid] = m;
@@ -189,6 +231,7 @@ prepass_kv_kernel(const PrepassParams p)
             }
         }
         __syncthreads();
+        SAGE_STAMP();                              // 4: head statistics reduced
         if (p.nslab > 1 && tid == 0 && !(SAGE_PP_ABL & 1)) {          // the last slab to leave re-arms the head's counters
             const unsigned left = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (left == (unsigned)p.nslab - 1) {
@@ -200,43 +243,61 @@ prepass_kv_kernel(const PrepassParams p)
     if (SAGE_PP_ABL & 2) {
         unsigned acc = 0;
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int i = 0; i < NR; i++) acc += rw[c][i];
+        for (int i = 0; i < NR; i++) acc += rw[i][0] + rw[i][1];
         if (acc == 0x12345u) p.ws[0] = 1.0f;
         return;
     }
 
-    if (!is_v) {
+    if constexpr (!IS_V) {
         // ---- 3a. K: INT8 rows + group scales (the arithmetic of quant_int8_kernel, on the registers) --------------------
         const int blk = p.k_blk;                            // 64 / 128 keys per scale block (one group map per block)
         const int bsh = (blk == 128) ? 7 : 6;
         const int nb = kStatsSlab >> bsh;                   // blocks per slab
-        const int rb = blk / RPI;                           // rows of a thread inside one block (consecutive i): 2, 4 or 8
         const int ngroups = (p.k_gran == GR_BLOCK) ? 1 : 4 * (blk / p.k_warp);
         const bool smooth = p.k_mean != nullptr;
         const unsigned init_bits = (p.k_style == QS_CUDA) ? __float_as_uint(1e-7f) : 0u;    // fused.cu:147
         if (tid < 64) gmax[tid >> 3][tid & 7] = init_bits;
-        float mean4[4];
+        float mean4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned m01 = 0u, m23 = 0u;
+        if (smooth) {
+            m01 = (unsigned)kmean[c4] | ((unsigned)kmean[c4 + 1] << 16);
+            m23 = (unsigned)kmean[c4 + 2] | ((unsigned)kmean[c4 + 3] << 16);
 #pragma unroll
-        for (int j = 0; j < 4; j++) mean4[j] = smooth ? ld16<DT>(kmean[c4 + j]) : 0.0f;
+            for (int j = 0; j < 4; j++) mean4[j] = ld16<DT>(kmean[c4 + j]);
+        }
+        // rows past the end take the mean's bits: their smoothed value is exactly 0, so the two passes below need no per-row
+        // validity test (only the store does).  Unconditional selects, in place: a branch here makes the compiler keep two
+        // copies of the slab (64 more VGPRs) and spill.
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const bool valid = i < my_rows;
+            rw[i][0] = valid ? rw[i][0] : m01;
+            rw[i][1] = valid ? rw[i][1] : m23;
+        }
         __syncthreads();
         const int g_thread = group_of_row(r0 & (blk - 1), p.k_gran, p.k_warp);   // every row of a thread in a block: same group
         const int nblk_total = (L + blk - 1) >> bsh;
-        int8_t *out = p.k_out + (long)b * p.ko_sb + (long)h * p.ko_sh + (long)(row0 + r0) * p.ko_sl + c4;
+        // buffer stores: rows past the end of the head are dropped by the range check
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.k_out + (long)b * p.ko_sb + (long)h * p.ko_sh, 0, (unsigned)((long)(L - 1) * p.ko_sl + D), 0x00020000);
+        const unsigned ooff = (unsigned)((row0 + r0) * (int)p.ko_sl + c4), ostep = (unsigned)(RPI * (int)p.ko_sl);
 
         // STYLE: 0 the CUDA quantiser (fp32 difference, round-to-nearest-even, fused.cu:131-172), 1 Triton rounding with
-        // the epsilon scale (quant_per_thread.py:41-44), 2 Triton rounding, plain scale (quant_per_block.py:41-44)
-        auto quantise = [&](auto style_tag) {
+        // the epsilon scale (quant_per_thread.py:41-44) -- the two K conventions of the reference's CUDA entry points
+        auto quantise = [&](auto style_tag, auto smooth_tag) {
             constexpr int STYLE = decltype(style_tag)::value;
+            constexpr bool SMOOTH = decltype(smooth_tag)::value;
             // the 4 values of row i: (k - km), rounded to the input dtype unless the CUDA quantiser's fp32 difference is
             // asked for (quant_per_block.py:53-54 vs fused.cu:131-137); pre_scale is 1 for K
             auto row_values = [&](int i, float (&f)[4]) {
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const unsigned w = rw[c][i];
+                    unsigned w = rw[i][c];
+                    // every pass recomputes the values from the packed word; without this the compiler recognises the
+                    // common subexpressions and carries 128 unpacked floats from pass to pass (1096 VGPRs spilled)
+                    asm volatile("" : "+v"(w));
                     float lo = ld16<DT>((uint16_t)(w & 0xffffu)), hi = ld16<DT>((uint16_t)(w >> 16));
-                    if (smooth) {
+                    if constexpr (SMOOTH) {
                         lo -= mean4[2 * c];
                         hi -= mean4[2 * c + 1];
                         if (STYLE != 0) round_pair_to_dtype<DT>(lo, hi);
@@ -245,107 +306,134 @@ prepass_kv_kernel(const PrepassParams p)
                     f[2 * c + 1] = hi;
                 }
             };
-#pragma unroll 1
-            for (int kb = 0; kb < nb; kb++) {
-                float amax = 0.0f;
-#pragma unroll 1
-                for (int m = 0; m < rb; m += 2) {
+            // A thread's rows inside one scale block (rb of them, consecutive i) share their group, and so do the 32 lanes
+            // around it: rows r0 and r0 ^ 1 map to the same group in every granularity.  Accumulate per block, reduce over
+            // the half-wave with DPP, one LDS atomic per half-wave and block (one per thread and row pair serialised the LDS
+            // unit: 32 lanes per address, 16 us per workgroup in this pass alone).
+            const int rb_mask = (blk / RPI) - 1;                 // rows of a thread per block, minus 1 (1, 3 or 7)
+            float amax = 0.0f;
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = kb * rb + m + u;
-                        if (i < my_rows) {
-                            float f[4];
-                            row_values(i, f);
-#pragma unroll
-                            for (int j = 0; j < 4; j++) amax = fmaxf(amax, fabsf(f[j]));
-                        }
-                    }
+            for (int i = 0; i < NR; i++) {
+                float f[4];
+                row_values(i, f);
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
+                if ((i & 1) && ((i & rb_mask) == rb_mask)) {     // last row of the block (uniform; blocks hold >= 2 rows)
+                    float m = amax;
+                    m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0xB1, 0xf, 0xf, true)));    // lane ^ 1
+                    m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0x4E, 0xf, 0xf, true)));    // lane ^ 2
+                    m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0x141, 0xf, 0xf, true)));   // 7 - lane (of 8)
+                    m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0x140, 0xf, 0xf, true)));   // 15 - lane (of 16)
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    if ((tid & 31) == 0) atomicMax(&gmax[(i * RPI) >> bsh][g_thread], __float_as_uint(m));
+                    amax = 0.0f;
                 }
-                if (kb * rb < my_rows) atomicMax(&gmax[kb][g_thread], __float_as_uint(amax));
+                asm volatile("" ::: "memory");              // keep the rows in order: hoisting them all spills
             }
             __syncthreads();
+            SAGE_STAMP();                          // 5 (K): group maxima
             if (tid < nb * ngroups) {
                 const int kb = tid / ngroups, g = tid % ngroups;
                 const int gb = slab * nb + kb;
-                if (gb < nblk_total)
-                    p.k_scale[(bh * nblk_total + gb) * ngroups + g] = quant_scale(__uint_as_float(gmax[kb][g]), p.k_style);
-            }
-#pragma unroll 1
-            for (int kb = 0; kb < nb; kb++) {
-                const float am = __uint_as_float(gmax[kb][g_thread]);
-                const float inv = 127.0f / am;                               // fused.cu:164
+                const float am = __uint_as_float(gmax[kb][g]);
                 const float sc = quant_scale(am, p.k_style);
-                const float y = quant_recip(sc);
-#pragma unroll 1
-                for (int m = 0; m < rb; m += 2) {
+                gsc[kb][g] = sc;
+                gy[kb][g] = (STYLE == 0) ? 127.0f / am : quant_recip(sc);       // fused.cu:164
+                if (gb < nblk_total) p.k_scale[(bh * nblk_total + gb) * ngroups + g] = sc;
+            }
+            __syncthreads();
+            unsigned orun = ooff;
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = kb * rb + m + u;
-                        if (i >= my_rows) continue;
-                        float f[4];
-                        row_values(i, f);
-                        int q[4];
+            for (int i = 0; i < NR; i += 2) {
+                const float sc = gsc[(i * RPI) >> bsh][g_thread], y = gy[(i * RPI) >> bsh][g_thread];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if constexpr (STYLE == 0) q[j] = quant_round_cuda(f[j], inv);
-                            else if constexpr (STYLE == 1) q[j] = quant_round_triton_nz(f[j], sc, y);
-                            else q[j] = quant_round_triton(f[j], sc, y);
-                        }
-                        *reinterpret_cast<unsigned *>(out + (long)(i * RPI) * p.ko_sl) = pack_int8x4(q[0], q[1], q[2], q[3]);
+                for (int u = 0; u < 2; u++) {
+                    float f[4];
+                    row_values(i + u, f);
+                    int q[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if constexpr (STYLE == 0) q[j] = quant_round_cuda(f[j], y);
+                        else q[j] = quant_round_triton_nz(f[j], sc, y);
                     }
+                    __builtin_amdgcn_raw_buffer_store_b32(pack_int8x4(q[0], q[1], q[2], q[3]), orsrc, orun, 0, 0);
+                    orun += ostep;
+                    asm volatile("" : "+v"(orun) :: "memory");
                 }
             }
         };
-        if (p.k_style == QS_CUDA) quantise(std::integral_constant<int, 0>{});
-        else if (p.k_style == QS_TRITON_THREAD) quantise(std::integral_constant<int, 1>{});
-        else quantise(std::integral_constant<int, 2>{});
+        // one instantiation per (rounding style, smooth_k?): no run-time branch inside the passes
+        auto by_smooth = [&](auto style_tag) {
+            if (smooth) quantise(style_tag, std::true_type{}); else quantise(style_tag, std::false_type{});
+        };
+        if (p.k_style == QS_CUDA) by_smooth(std::integral_constant<int, 0>{});
+        else by_smooth(std::integral_constant<int, 1>{});          // QS_TRITON_THREAD (checked by the C ABI)
     } else {
         // ---- 3b. V: FP8 tile image, two 64-token tiles per LDS stage (the arithmetic of prep_v_kernel) -------------------
         const bool smooth = p.v_mean != nullptr;
         const int ntiles = (L + BLKK - 1) / BLKK;
         unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 64);
         constexpr int RPS = 2 * BLKK / RPI;                 // rows of a thread per stage
-#pragma unroll 1
+#pragma unroll
         for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
-            if (row0 + s * 2 * BLKK >= L) break;            // workgroup-uniform
+            if (row0 + s * 2 * BLKK < L) {                  // workgroup-uniform
 #pragma unroll
-            for (int m = 0; m < RPS; m++) {
-                const int rs = r0 + m * RPI;                // row inside the stage (0..127)
-                const int i = s * RPS + m;
-                const v2u t = {rw[0][i], rw[1][i]};
-                *reinterpret_cast<v2u *>(&tile[rs >> 6][(rs & 63) * LDT + c4]) = t;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 2 * D * 4 / NT; it++) {
-                const int piece = tid + NT * it;
-                const int tt = piece / (D * 4), pin = piece % (D * 4);
-                const int d = pin >> 2, pc = pin & 3;
-                const int t = (row0 >> 6) + 2 * s + tt;
-                if (t >= ntiles) continue;
-                const int ch = swz_chunk<64>(d, pc);
-                const float mean = ch_mean[d], recp = ch_recp[d];
-                float f[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int tok = pv_token_of_position(16 * ch + j);
-                    float xv = ld16<DT>(tile[tt][tok * LDT + d]);
-                    if (smooth) xv = (t * BLKK + tok < L) ? xv - mean : 0.0f;      // padding stays zero
-                    xv *= recp;
-                    f[j] = fminf(fmaxf(xv, -448.0f), 448.0f);                      // satfinite
+                for (int m = 0; m < RPS; m++) {
+                    const int rs = r0 + m * RPI;            // row inside the stage (0..127)
+                    const v2u t = {rw[s * RPS + m][0], rw[s * RPS + m][1]};
+                    *reinterpret_cast<v2u *>(&tile[rs >> 6][(rs & 63) * LDT + c4]) = t;
                 }
-                v4u pk;
+                __syncthreads();
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
-                    word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
-                    pk[w] = (unsigned)word;
+                for (int it = 0; it < 2 * D * 4 / NT; it++) {
+                    const int piece = tid + NT * it;
+                    const int tt = piece / (D * 4), pin = piece % (D * 4);
+                    const int d = pin >> 2, pc = pin & 3;
+                    const int t = (row0 >> 6) + 2 * s + tt;
+                    if (t >= ntiles) continue;
+                    const int ch = swz_chunk<64>(d, pc);
+                    const float mean = ch_mean[d], recp = ch_recp[d];
+                    float f[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int tok = pv_token_of_position(16 * ch + j);
+                        float xv = ld16<DT>(tile[tt][tok * LDT + d]);
+                        if (smooth) xv = (t * BLKK + tok < L) ? xv - mean : 0.0f;      // padding stays zero
+                        xv *= recp;
+                        f[j] = fminf(fmaxf(xv, -448.0f), 448.0f);                      // satfinite
+                    }
+                    v4u pk;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
+                        word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
+                        pk[w] = (unsigned)word;
+                    }
+                    *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
                 }
-                *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
+#if SAGE_PP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (is_v) tslot = 6;
+    SAGE_STAMP();                                  // 6: stores acknowledged
+    if (tid == 0) trace[7] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) |              // XCC_ID
+                              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);     // HW_ID
+#endif
+}
+
+template <int D, int DT>
+__global__ void __launch_bounds__(kPrepassThreads, 4)
+prepass_kv_kernel(const PrepassParams p)
+{
+    __shared__ PrepassLds<D> lds;
+    // dispatch order: every head of K of one batch element, then every head of its V (alternating K and V heads instead
+    // measured the same at C3 and 15 % slower at B=16 H=32 N=1024)
+    const int is_v = (p.parts == 3) ? (int)(blockIdx.z & 1) : (p.parts == 2);
+    const int b = (p.parts == 3) ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
+    if (is_v) prepass_body<D, DT, true>(p, lds, b);
+    else prepass_body<D, DT, false>(p, lds, b);
 }
 
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t s)
