@@ -221,7 +221,7 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
     if arch.startswith(_SUPPORTED_ARCH_PREFIX):
         return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
                                             return_lse=return_lse, pv_accum_dtype="fp32+fp32", split_kv=kwargs.get("split_kv"),
-                                            fused_prepass=kwargs.get("fused_prepass", False))
+                                            fused_prepass=kwargs.get("fused_prepass"))
     raise ValueError(f"Unsupported architecture: {arch} (sageattention_amd targets gfx950 / MI355X only)")
 
 
@@ -308,22 +308,59 @@ def _sm_log2(sm_scale: float) -> float:
     return ctypes.c_float(ctypes.c_float(sm_scale).value * ctypes.c_float(1.44269504088896340736).value).value
 
 
-def _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale, blkk=64):
-    """Returns (q_int8, q_scale, k_int8, k_scale, gran code, q_warp, sm_scale_log2).  ``warpq`` (32 / 16) and ``blkk`` (64 /
-    128) are the reference kernels' scale-group sizes (core.py:602-604, 964-970); the row -> group maps do not depend on the
-    q block size, so BLKQ = 128 here also reproduces the sm90 kernels' BLKQ = 64 groups."""
+def _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale, blkk=64):
+    """INT8 Q for the CUDA-named entry points.  Returns (q_int8, q_scale, gran code, q_warp, sm_scale_log2).  ``warpq``
+    (32 / 16) and ``blkk`` (64 / 128) are the reference kernels' scale-group sizes (core.py:602-604, 964-970); the
+    row -> group maps do not depend on the q block size, so BLKQ = 128 here also reproduces the sm90 kernels' BLKQ = 64 groups."""
     kflag = _cabi.GRAN_KBLK128 if blkk == 128 else 0
-    if qk_quant_gran == "per_warp":
-        return (*per_warp_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=blkk),
-                _cabi.GRAN_PER_WARP | kflag, warpq, _sm_log2(sm_scale))
-    if qk_quant_gran == "per_thread":
-        return (*per_thread_int8(q, k, km, tensor_layout=tensor_layout, BLKQ=128, WARPQ=warpq, BLKK=blkk, WARPK=blkk),
-                _cabi.GRAN_PER_THREAD | kflag, warpq, _sm_log2(sm_scale))
+    if qk_quant_gran == "per_warp":            # quant.py:105-180 (q half)
+        q_int8, q_scale = _quant(q, None, 128, warpq, _cabi.GRAN_PER_WARP, False, _cabi.QSTYLE_CUDA, 1.0, tensor_layout, 128 // warpq)
+        return q_int8, q_scale, _cabi.GRAN_PER_WARP | kflag, warpq, _sm_log2(sm_scale)
+    if qk_quant_gran == "per_thread":          # quant_per_thread.py:154-203 (q half)
+        q_int8, q_scale = _quant(q, None, 128, warpq, _cabi.GRAN_PER_THREAD, False, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout,
+                                 (128 // warpq) * 8)
+        return q_int8, q_scale, _cabi.GRAN_PER_THREAD | kflag, warpq, _sm_log2(sm_scale)
     if blkk != 64:
         raise ValueError("per_block scales are defined for 64-key groups only")
-    # "per_block": gfx950 extension (the Triton path's granularity with the CUDA rounding)
-    return (*per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout, quantization_backend="cuda"),
-            _cabi.GRAN_PER_BLOCK, 128, 1.0)
+    # "per_block": gfx950 extension (the Triton path's granularity with the CUDA rounding); sm_scale * log2e folded into q
+    q_int8, q_scale = _quant(q, None, 128, 128, _cabi.GRAN_PER_BLOCK, False, _cabi.QSTYLE_CUDA, sm_scale * LOG2E, tensor_layout, 1)
+    return q_int8, q_scale, _cabi.GRAN_PER_BLOCK, 128, 1.0
+
+
+def _fused_prepass_wanted(k, tensor_layout: str, override: Optional[bool]) -> bool:
+    """Whether the K / V pre-pass runs as the one-launch, single-read kernel (``sage_prepass_kv``) or as the
+    mean -> quantise -> statistics -> image sequence.  Same bits either way.  Measured on MI355X
+    (profiles/r2_run_r3g_prepass_sweep.txt): the one launch wins from 512 keys up (129 vs 151 us at B=2 H=32 N=8192 D=128, 77 vs
+    108 us at H=8 N=32768, 2x on launch-bound small calls) and loses only when very many heads of <= 256 keys leave its
+    512-row slabs half empty (57 vs 47 us at B=64 H=16 N=256 D=64)."""
+    if not prepass_fused_ok(k, tensor_layout):
+        return False
+    if override is not None:
+        return bool(override)
+    B, H, L = _dims(k, tensor_layout)[:3]
+    return L > 256 or B * H <= 256
+
+
+def _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, blkk, smooth_k, smooth_v, return_lse, fused: bool, v_fp8: bool = True):
+    """K mean + INT8 K (+ FP8 V image when ``v_fp8``).  Returns (lse_correction, km [B,H,D] | None, k_int8, k_scale, v_image,
+    v_scale, vm); the K conventions are those of ``per_thread_int8`` / ``per_warp_int8`` / ``per_block_int8(cuda)``."""
+    if fused:
+        km_s, k_int8, k_scale, v_image, v_scale, vm = prepass_kv_fp8(k, v if v_fp8 else None, tensor_layout, smooth_k=smooth_k,
+                                                                     smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=qk_quant_gran)
+        lse_correction = None
+        if smooth_k and return_lse:
+            lse_correction = _lse_correction(q, km_s.unsqueeze(1 if tensor_layout == "NHD" else 2), tensor_layout)
+        return lse_correction, km_s, k_int8, k_scale, v_image, v_scale, vm
+    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    km_s = _squeeze_km(km, tensor_layout)
+    if qk_quant_gran == "per_thread":
+        k_int8, k_scale = _quant(k, km_s, blkk, blkk, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
+    else:
+        k_int8, k_scale = _quant(k, km_s, blkk, blkk, _cabi.GRAN_PER_BLOCK, True, _cabi.QSTYLE_CUDA, 1.0, tensor_layout, 1)
+    v_image = v_scale = vm = None
+    if v_fp8:
+        v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+    return lse_correction, km_s, k_int8, k_scale, v_image, v_scale, vm
 
 
 def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal: bool = False,
@@ -345,12 +382,14 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
     if sm_scale is None:
         sm_scale = head_dim_og ** -0.5
-    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
     if pv_accum_dtype in ["fp32", "fp16+fp32"] and smooth_v:
         warnings.warn(f"pv_accum_dtype is {pv_accum_dtype}, smooth_v will be ignored.")   # core.py:608-610
         smooth_v = False
     warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32") else 32              # core.py:602-604
-    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, warpq, sm_scale)
+    fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass"))
+    lse_correction, _, k_int8, k_scale, _, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
+                                                              fused, v_fp8=False)
+    q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale)
     vm = None
     if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
         v_image, vm = sub_mean(v, tensor_layout)
@@ -386,21 +425,13 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         warnings.warn(f"pv_accum_dtype is '{pv_accum_dtype}', smooth_v will be ignored.")   # core.py:797-803
         smooth_v = False
     fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
+    fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")) and k.shape == v.shape
     if fuse_q:
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM).
         # (Running the V pre-pass on a side stream beside the K chain was measured and rejected: the two HBM-bound chains
         #  slow each other down and the cross-stream joins cost more than the launch gaps they hide, 956 -> 1130 us at C3.)
-        if kwargs.get("fused_prepass", False) and prepass_fused_ok(k, tensor_layout) and k.shape == v.shape:
-            # opt-in: the whole K / V pre-pass as one launch that reads K and V once (sage_prepass_kv) -- same bits; measured
-            # slower than the six launches at the BASELINE shapes (177 vs 155 us at C3), hence opt-in
-            km_s, k_int8, k_scale, v_image, v_scale, vm = prepass_kv_fp8(k, v, tensor_layout, smooth_k=smooth_k, smooth_v=smooth_v)
-            km = None if km_s is None else km_s.unsqueeze(1 if tensor_layout == "NHD" else 2)
-            lse_correction = _lse_correction(q, km, tensor_layout) if (smooth_k and return_lse) else None
-        else:
-            km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-            km_s = _squeeze_km(km, tensor_layout)
-            k_int8, k_scale = _quant(k, km_s, 64, 64, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, tensor_layout, 4)
-            v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+        lse_correction, _, k_int8, k_scale, v_image, v_scale, vm = _prepass_kv(q, k, v, tensor_layout, "per_thread", 64, smooth_k, smooth_v,
+                                                                               return_lse, fused)
         B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
         n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
         if n_split:
@@ -410,9 +441,9 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
             o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
                                    return_lse, v_mean=vm)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
-    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 32, sm_scale)
-    v_image, v_scale, vm = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=smooth_v)
+    lse_correction, _, k_int8, k_scale, v_image, v_scale, vm = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, smooth_v,
+                                                                           return_lse, fused)
+    q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 32, sm_scale)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
                          gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
@@ -439,9 +470,10 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_ca
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
     if sm_scale is None:
         sm_scale = head_dim_og ** -0.5
-    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
-    q_int8, q_scale, k_int8, k_scale, gran, q_warp, sm_log2 = _quant_qk(q, k, km, qk_quant_gran, tensor_layout, 16, sm_scale, blkk=128)
-    v_image, v_scale, _ = per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=448.0, smooth_v=False)
+    fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")) and k.shape == v.shape
+    lse_correction, _, k_int8, k_scale, v_image, v_scale, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 128, smooth_k, False,
+                                                                          return_lse, fused)
+    q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 16, sm_scale, blkk=128)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
                          gran, q_warp, sm_log2, True, return_lse)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)

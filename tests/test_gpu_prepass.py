@@ -118,16 +118,44 @@ def test_graph_capture_replays():
             _same(a, b, name + " (graph replay)")
 
 
-@pytest.mark.parametrize("layout,causal", [("HND", True), ("NHD", False)])
-def test_sageattn_with_fused_prepass_is_bit_equal(layout, causal):
+ENTRY_CASES = [  # entry point, kwargs
+    ("sageattn", dict()),
+    ("sageattn_qk_int8_pv_fp8_cuda", dict(qk_quant_gran="per_warp", pv_accum_dtype="fp32+fp32")),
+    ("sageattn_qk_int8_pv_fp8_cuda", dict(qk_quant_gran="per_thread", pv_accum_dtype="fp32", smooth_v=True)),
+    ("sageattn_qk_int8_pv_fp8_cuda", dict(qk_quant_gran="per_block", pv_accum_dtype="fp32+fp16", smooth_k=False)),
+    ("sageattn_qk_int8_pv_fp8_cuda_sm90", dict(qk_quant_gran="per_thread")),
+    ("sageattn_qk_int8_pv_fp8_cuda_sm90", dict(qk_quant_gran="per_warp")),
+    ("sageattn_qk_int8_pv_fp16_cuda", dict(qk_quant_gran="per_thread", pv_accum_dtype="fp32")),
+    ("sageattn_qk_int8_pv_fp16_cuda", dict(qk_quant_gran="per_warp", pv_accum_dtype="fp16+fp32")),
+]
+
+
+@pytest.mark.parametrize("entry,extra", ENTRY_CASES)
+@pytest.mark.parametrize("layout,causal,D", [("HND", True, 128), ("NHD", False, 64)])
+def test_entry_points_are_bit_equal_with_either_prepass(entry, extra, layout, causal, D):
+    """Every dense entry point gives the same bits whether its pre-pass is the one launch or the kernel sequence."""
     import sageattention_amd as sa
     g = torch.Generator(device="cuda").manual_seed(21)
-    shape = (2, 4, 1500, 128) if layout == "HND" else (2, 1500, 4, 128)
+    shape = (2, 4, 1500, D) if layout == "HND" else (2, 1500, 4, D)
     q, k, v = (torch.randn(shape, device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(3))
     k = k + 0.75
-    kw = dict(tensor_layout=layout, is_causal=causal, return_lse=True)
-    call = lambda **e: sa.sageattn(q, k, v, **kw, **e)
-    o0, l0 = call()
-    o1, l1 = call(fused_prepass=True)
+    fn = getattr(sa, entry)
+    kw = dict(tensor_layout=layout, is_causal=causal, return_lse=True, **extra)
+    o0, l0 = fn(q, k, v, fused_prepass=False, **kw)
+    o1, l1 = fn(q, k, v, fused_prepass=True, **kw)
+    o2, l2 = fn(q, k, v, **kw)                     # the default picks one of the two
     _same(o1, o0, "o")
     _same(l1, l0, "lse")
+    _same(o2, o0, "o (default)")
+    _same(l2, l0, "lse (default)")
+
+
+def test_default_prepass_choice():
+    from sageattention_amd import core
+    mk = lambda *s: torch.empty(*s, device="cuda", dtype=torch.float16)
+    assert core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", None)
+    assert core._fused_prepass_wanted(mk(1, 4, 200, 64), "HND", None)            # few heads: one launch instead of six
+    assert not core._fused_prepass_wanted(mk(64, 16, 256, 64), "HND", None)      # many half-empty slabs
+    assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", None)      # beyond the in-launch barrier's reach
+    assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", True)
+    assert not core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", False)
