@@ -53,6 +53,23 @@ template <int DT> __device__ __forceinline__ void round_pair_to_dtype(float &a, 
 
 constexpr int kPrepassThreads = 512;
 
+// the same rounding, left packed (low half = a)
+template <int DT> __device__ __forceinline__ unsigned pack_pair_to_dtype(float a, float b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    unsigned u;
+    if constexpr (DT == DT_BF16) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const b2 r = __builtin_convertvector(f2{a, b}, b2);
+        __builtin_memcpy(&u, &r, 4);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 r = __builtin_convertvector(f2{a, b}, h2);
+        __builtin_memcpy(&u, &r, 4);
+    }
+    return u;
+}
+
 template <int D>
 struct PrepassLds {
     static constexpr int TPR = D / 4, RPI = kPrepassThreads / TPR, LDT = D + 8;
@@ -99,7 +116,6 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
     const int row0 = slab * kStatsSlab;
     const int end = min(L, row0 + kStatsSlab);
-    const bool full = end - row0 == kStatsSlab;                 // workgroup-uniform: every row of the slab exists
     const int my_rows = (end - row0 - r0 + RPI - 1) / RPI;      // rows i < my_rows of this thread exist (may be <= 0)
 #if SAGE_PP_TRACE
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(p.ws + 2L * p.B * p.H * p.nslab * 3 * D) +
@@ -143,18 +159,22 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         float mx[4], mn[4], sm[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; sm[j] = 0.0f; }
-        // rows past the end read as zeros: exact for the sums; selects keep them out of max / min.  (One loop for whole and
-        // partial slabs: a specialised copy for whole slabs saves the selects but tips the register allocation into spilling.)
+        // Rows past the end read as zeros: exact for the sums.  K only needs the sums (its mean).  For V a per-row penalty
+        // (0 for a row that exists, -inf otherwise) is added for the max and subtracted for the min -- two full-rate adds
+        // where a select per value (v_cndmask_b32: ~22 cycles per wave on gfx950, profiles/r2_run1_ubench2.txt) cost 4x more.
         if (!(SAGE_PP_ABL & 4)) {
 #pragma unroll
             for (int i = 0; i < NR; i++) {
-                const bool valid = full || i < my_rows;
+                float pen = 0.0f;
+                if constexpr (IS_V) pen = __uint_as_float((unsigned)((my_rows - 1 - i) >> 31) & 0xff800000u);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const unsigned w = rw[i][c];
                     const float lo = ld16<DT>((uint16_t)(w & 0xffffu)), hi = ld16<DT>((uint16_t)(w >> 16));
-                    mx[2 * c] = fmaxf(mx[2 * c], valid ? lo : -INFINITY);         mn[2 * c] = fminf(mn[2 * c], valid ? lo : INFINITY);
-                    mx[2 * c + 1] = fmaxf(mx[2 * c + 1], valid ? hi : -INFINITY); mn[2 * c + 1] = fminf(mn[2 * c + 1], valid ? hi : INFINITY);
+                    if constexpr (IS_V) {
+                        mx[2 * c] = fmaxf(mx[2 * c], lo + pen);         mn[2 * c] = fminf(mn[2 * c], lo - pen);
+                        mx[2 * c + 1] = fmaxf(mx[2 * c + 1], hi + pen); mn[2 * c + 1] = fminf(mn[2 * c + 1], hi - pen);
+                    }
                     sm[2 * c] += lo;
                     sm[2 * c + 1] += hi;
                 }
@@ -188,27 +208,32 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             if (tid == 0) {
                 __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nslab)
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(2);
             }
             __syncthreads();
         }
         SAGE_STAMP();                              // 3: every slab of the head has arrived
         if (tid < D) {
-            // slabs in index order; eight slabs' loads are in flight together (one round trip to the coherence point per batch,
+            // slabs in index order; sixteen slabs' loads are in flight together (one round trip to the coherence point per batch,
             // not one per slab: with the loads issued one by one this loop alone cost ~2 us x nslab per workgroup)
             float a = -INFINITY, c = INFINITY, s = 0.0f;
-            for (int i0 = 0; i0 < p.nslab; i0 += 8) {
-                float va[8], vc[8], vs[8];
+            for (int i0 = 0; i0 < p.nslab; i0 += 16) {
+                float va[16], vc[16], vs[16];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 16; u++) {
                     const float *wi = ws + (long)min(i0 + u, p.nslab - 1) * 3 * D;
-                    va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vc[u] = __hip_atomic_load(wi + D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (IS_V) {
+                        va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vc[u] = __hip_atomic_load(wi + D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     vs[u] = __hip_atomic_load(wi + 2 * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (i0 + u < p.nslab) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); s += vs[u]; }
+                for (int u = 0; u < 16; u++) {
+                    if (i0 + u < p.nslab) {
+                        if constexpr (IS_V) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); }
+                        s += vs[u];
+                    }
                 }
             }
             if constexpr (!IS_V) {
@@ -265,14 +290,13 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 #pragma unroll
             for (int j = 0; j < 4; j++) mean4[j] = ld16<DT>(kmean[c4 + j]);
         }
-        // rows past the end take the mean's bits: their smoothed value is exactly 0, so the two passes below need no per-row
-        // validity test (only the store does).  Unconditional selects, in place: a branch here makes the compiler keep two
-        // copies of the slab (64 more VGPRs) and spill.
+        // rows past the end (zeros from the buffer loads) take the mean's bits: their smoothed value is exactly 0, so the two
+        // passes below need no per-row validity test.  In place and without selects: OR with the mean under a sign mask.
 #pragma unroll
         for (int i = 0; i < NR; i++) {
-            const bool valid = i < my_rows;
-            rw[i][0] = valid ? rw[i][0] : m01;
-            rw[i][1] = valid ? rw[i][1] : m23;
+            const unsigned gone = (unsigned)((my_rows - 1 - i) >> 31);       // all ones when row i does not exist
+            rw[i][0] |= m01 & gone;
+            rw[i][1] |= m23 & gone;
         }
         __syncthreads();
         const int g_thread = group_of_row(r0 & (blk - 1), p.k_gran, p.k_warp);   // every row of a thread in a block: same group
@@ -312,13 +336,36 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             // unit: 32 lanes per address, 16 us per workgroup in this pass alone).
             const int rb_mask = (blk / RPI) - 1;                 // rows of a thread per block, minus 1 (1, 3 or 7)
             float amax = 0.0f;
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            us2 amax16 = {0, 0};
 #pragma unroll
             for (int i = 0; i < NR; i++) {
-                float f[4];
-                row_values(i, f);
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
+                if constexpr (STYLE == 0) {
+                    float f[4];
+                    row_values(i, f);
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
+                } else {
+                    // values rounded to the input dtype (quant_per_block.py:53-54): the word is overwritten with the smoothed,
+                    // rounded pair (pass 2 only unpacks it) and the abs-max runs on the 16-bit patterns, which order like
+                    // unsigned integers in a sign-magnitude format
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        unsigned u = rw[i][c];
+                        if constexpr (SMOOTH) {
+                            asm volatile("" : "+v"(u));
+                            const float lo = ld16<DT>((uint16_t)(u & 0xffffu)) - mean4[2 * c];
+                            const float hi = ld16<DT>((uint16_t)(u >> 16)) - mean4[2 * c + 1];
+                            u = pack_pair_to_dtype<DT>(lo, hi);
+                        }
+                        const unsigned mag = u & 0x7fff7fffu;
+                        us2 m2;
+                        __builtin_memcpy(&m2, &mag, 4);
+                        amax16 = __builtin_elementwise_max(amax16, m2);
+                    }
+                }
                 if ((i & 1) && ((i & rb_mask) == rb_mask)) {     // last row of the block (uniform; blocks hold >= 2 rows)
                     float m = amax;
+                    if constexpr (STYLE != 0) { m = ld16<DT>(amax16[0] > amax16[1] ? amax16[0] : amax16[1]); amax16 = us2{0, 0}; }
                     m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0xB1, 0xf, 0xf, true)));    // lane ^ 1
                     m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0x4E, 0xf, 0xf, true)));    // lane ^ 2
                     m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(m), 0x141, 0xf, 0xf, true)));   // 7 - lane (of 8)
