@@ -140,7 +140,9 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  * sage_quant_qk_int8 + sage_prep_v_fp8 sequence (6 launches, 4 B/elt read): same per-slab summation order.
  *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
  *   sync  sage_prepass_sync_words(B,H) uint32, ZERO before the first call; the kernel leaves it zero again, so calls issued
- *         in stream order may share it -- concurrent calls (other streams) need their own
+ *         in stream order may share it -- concurrent calls (other streams) need their own.  Layout: 32 words per (K|V, b, h):
+ *         [0] arrivals, [1] departures, [2] sticky flag set if a workgroup waited ~1 s for its head in vain (results
+ *         of that call are then wrong; never observed -- a debugging aid, the kernel does not clear it)
  *   L     at most sage_prepass_max_seqlen() (32768): the slabs of a head wait for each other inside the launch; longer
  *         sequences take the three-call sequence (SAGE_EINVAL here)
  */

@@ -18,7 +18,8 @@
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.
 // The two counters of a head return to zero before the kernel ends, so one zero-initialised sync buffer serves every
-// call issued in stream order.
+// call issued in stream order.  The wait is bounded: after ~1 s a workgroup gives up, sets word 2 of the head's sync line
+// (sticky, never cleared by the kernel) and carries on with whatever partials it finds.
 #include "sage_common.h"
 #include "sage_kernels.h"
 #include "sage_quant_math.h"
@@ -207,8 +208,13 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nslab)
+                // bounded (about a second): if the forward-progress assumption above were ever violated the launch would
+                // finish with wrong numbers and a sticky flag in the head's sync line instead of hanging the device
+                unsigned polls = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nslab) {
                     __builtin_amdgcn_s_sleep(2);
+                    if (++polls > (1u << 20)) { __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
             }
             __syncthreads();
         }

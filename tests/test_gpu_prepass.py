@@ -65,7 +65,7 @@ def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth
         for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, f"{name} (call {rep})")
     key = (torch.cuda.current_device(), torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
-    assert int(quant._sync_cache[key].abs().sum().item()) == 0
+    assert int(quant._sync_cache[key].abs().sum().item()) == 0           # counters re-armed, no give-up flag
 
 
 def test_k_half_only_and_side_stream():
@@ -159,3 +159,35 @@ def test_default_prepass_choice():
     assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", None)      # beyond the in-launch barrier's reach
     assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", True)
     assert not core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", False)
+
+
+def _sync_flags():
+    return sum(int(b.abs().sum().item()) for b in quant._sync_cache.values())
+
+
+def test_head_barrier_makes_progress_while_other_kernels_hold_the_chip():
+    """The in-launch barrier needs every slab of the lowest unfinished head to get a slot.  Crowd the device: a long attention
+    call and a second pre-pass on other streams while the pre-pass under test runs; it must finish, bit-equal, with its sync
+    buffer back at zero (a workgroup that gave up waiting would leave its sticky flag)."""
+    import sageattention_amd as sa
+    k, v = _mk(2, 32, 8192, 128, torch.bfloat16, "HND", 17)
+    ref = _sequence(k, v, "HND", True, False, 64, "per_thread")
+    qa = torch.randn(1, 32, 16384, 128, device="cuda", dtype=torch.bfloat16)
+    k2, v2 = _mk(1, 16, 32768, 128, torch.bfloat16, "HND", 23)
+    ref2 = _sequence(k2, v2, "HND", True, True, 64, "per_thread")
+    torch.cuda.synchronize()
+    s_attn, s_pp = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(4):
+        with torch.cuda.stream(s_attn):
+            sa.sageattn(qa, qa, qa, is_causal=False)                      # ~5 ms of attention workgroups on every CU
+        with torch.cuda.stream(s_pp):
+            got2 = quant.prepass_kv_fp8(k2, v2, "HND", smooth_k=True, smooth_v=True)      # 64-slab heads
+        outs.append((quant.prepass_kv_fp8(k, v, "HND", smooth_k=True), got2))
+    torch.cuda.synchronize()
+    for got, got2 in outs:
+        for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+            _same(a, b, name)
+        for a, b, name in zip(got2, ref2, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+            _same(a, b, name + " (64-slab heads, side stream)")
+    assert _sync_flags() == 0
