@@ -135,6 +135,30 @@ def e2e_step(cfg, q, k, v):
     return sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=cfg["causal"], pv_accum_dtype="fp32")
 
 
+def prepass_roofline(cfg, k, v, config_name):
+    """The second kernel of a sageattn() call: the one-launch K / V pre-pass (sage_prepass_kv), HBM-bound by its
+    arithmetic (2 B/element read + 1 B/element written for K and for V).  Average launch duration from HIP events."""
+    from sageattention_amd import quant as sq
+    if cfg["pv"] != "fp8" or not sq.prepass_fused_ok(k):
+        return None
+    for _ in range(5):
+        sq.prepass_kv_fp8(k, v)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    a.record()
+    for _ in range(reps):
+        sq.prepass_kv_fp8(k, v)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    nbytes = 2 * 3 * k.numel()
+    return {"kernel": "prepass_kv_kernel", "bound": "hbm", "avg_launch_ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes,
+            "traffic": 405.0e6 if config_name == "c3" else None,
+            "traffic_note": "PMC passes, profiles/r2_run_r3j_pmc_prepass_c3.txt" if config_name == "c3" else None}
+
+
 def timed(fn, steps, warmup, dist_on, ramp_s=0.0):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides; also per-step HIP
     event durations (events recorded on the stream the kernels are launched on = torch's current).
@@ -350,6 +374,7 @@ def main():
     wall_k, dev_k = timed(lambda: kernel_only_step(cfg, ops, sm_scale), args.steps, args.warmup, dist_on, args.ramp_seconds)
     wall_e, dev_e = timed(lambda: e2e_step(cfg, q, k, v), max(3, args.steps // 2), 2, dist_on, args.ramp_seconds)
     e2e_steps = max(3, args.steps // 2)
+    prepass = prepass_roofline(cfg, k, v, args.config)
 
     stats = torch.tensor([wall_k, wall_e], dtype=torch.float64, device=device)
     if dist_on:
@@ -381,7 +406,8 @@ def main():
                      "peak_note": "harmonic blend of the dense MFMA peaks of the two halves: INT8 5.0 POPS (QK^T) and " + ("FP8 5.0 PF (MX-scaled instruction)" if cfg["pv"] == "fp8" else "FP16 2.5 PF") + " (PV)"},
         "end_to_end": {"ms_per_call": round(wall_e / e2e_steps * 1e3, 4),
                        "tflops": round(fl * world / (wall_e / e2e_steps) / 1e12, 2),
-                       "what": "sageattn(): K mean + INT8 Q/K quant + V pre-pass + attention"},
+                       "what": "sageattn(): K mean + INT8 Q/K quant + V pre-pass + attention",
+                       "prepass": prepass},
     }
     if rank == 0:
         try:
