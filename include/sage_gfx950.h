@@ -143,7 +143,8 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *         in stream order may share it -- concurrent calls (other streams) need their own.  Layout: 32 words per (K|V, b, h):
  *         [0] arrivals, [1] departures, [2] sticky flag set if a workgroup waited ~1 s for its head in vain (results
  *         of that call are then wrong; never observed -- a debugging aid, the kernel does not clear it)
- *   L     at most sage_prepass_max_seqlen() (32768): the slabs of a head wait for each other inside the launch; longer
+ *   L     at most sage_prepass_max_seqlen() (32768 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
+ *         head wait for each other inside the launch, so all of them must fit on the device at once; longer
  *         sequences take the three-call sequence (SAGE_EINVAL here)
  */
 SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D);

@@ -241,7 +241,23 @@ SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D)
 
 SAGE_API int64_t sage_prepass_sync_words(int B, int H) { return 2 * (int64_t)B * H * sage::kPrepassSyncStride; }
 
-SAGE_API int sage_prepass_max_seqlen(void) { return sage::kPrepassMaxSlabs * sage::kStatsSlab; }
+// Longest head the in-launch barrier takes on the current device: at most kPrepassMaxSlabs slabs, and never more than one per
+// compute unit of the device (or partition) the caller runs on -- every slab of a head must be able to be resident while its
+// head-mates arrive, with room left for the workgroups of the heads before it (2 resident workgroups per CU at D = 128).
+SAGE_API int sage_prepass_max_seqlen(void)
+{
+    static thread_local int cached_dev = -1, cached_len = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        const int slabs = cus < sage::kPrepassMaxSlabs ? cus : sage::kPrepassMaxSlabs;
+        cached_len = slabs * sage::kStatsSlab;
+        cached_dev = dev;
+    }
+    return cached_len;
+}
 
 SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
                     void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
