@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 7
+#define SAGE_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -256,6 +256,16 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
                                      int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+
+/* FP16-PV attention (FP32 accumulation, "per-thread" granularity) with the same fused Q quantisation: bit-identical to
+ * sage_quant_qk_int8 + sage_attn_qk_int8_pv_f16(pv_accum = single).  v_image from sage_prep_v_f16; v_mean nullable [B,Hkv,D].
+ * Replaces: quant_per_thread.py:154-188 (the q half) + qk_int8_sv_f16_accum_f32_attn (core.py:598-625). */
+SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                      const float *k_scale, const float *v_mean,
+                                      int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                      int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
 
 /* The same kernel over a key range split into kv_split chunks of Lk_chunk keys each (a whole number of 64-key tiles), folded
  * into the kv-head dimension: k / k_scale / v_image / v_scale / v_mean are the operands of the unsplit call viewed as

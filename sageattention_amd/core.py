@@ -24,6 +24,7 @@ from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, ch
                     per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
+_FUSE_Q16_DEFAULT = __import__("os").environ.get("SAGE_FUSE_Q16", "1") != "0"      # debugging switch
 
 
 def get_gcn_arch(device: torch.device) -> str:
@@ -105,6 +106,13 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
+    if v_scale is None:            # FP16 PV (v_image from prep_v_fp16), straight FP32 accumulation
+        rc = _cabi.load().sage_attn_fused_q_pv_f16(
+            _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
+            B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+            int(is_causal), float(sm_scale_log2), code, code, _stream(q))
+        _cabi.check(rc, "sage_attn_fused_q_pv_f16")
+        return o, lse
     rc = _cabi.load().sage_attn_fused_q_pv_f8(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_scale), _p(v_mean),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
@@ -389,13 +397,18 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass"))
     lse_correction, _, k_int8, k_scale, _, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
                                                               fused, v_fp8=False)
-    q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale)
     vm = None
     if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
         v_image, vm = sub_mean(v, tensor_layout)
         vm = vm.float()
     else:
         v_image = prep_v_fp16(v, tensor_layout)
+    if qk_quant_gran == "per_thread" and pv_accum_dtype != "fp16+fp32" and kwargs.get("fuse_q_quant", _FUSE_Q16_DEFAULT):
+        # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM, one launch less)
+        o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
+                               return_lse, v_mean=vm)
+        return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
+    q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale)
     o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
                          gran, q_warp, sm_log2, pv_accum_dtype == "fp16+fp32", return_lse, v_mean=vm)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)

@@ -1457,6 +1457,13 @@ sage_attn_kernel(const AttnParams p)
                     const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
                     unsigned char *vsn = smem + nxt * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *vt = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES;
+                    // V(it+1) lands in the V region of slot nxt, which held V(it-2): the tile whose fragments the LAST loop
+                    // iteration read (late in its body: channel tiles 2, 3).  Every wave must be past those reads before any
+                    // wave's DMA may overwrite them -- inside the loop the barrier at the top of the body orders this; here
+                    // nothing did, and a fast wave could corrupt a slow wave's last PV (seen as 32 rows x channels 64..127 of
+                    // one head differing between two identical calls, once in a few hundred launches).
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
 #pragma unroll
                     for (int i = 0; i < VP / 4; i++) {
                         const int pc_ = wave * (VP / 4) + i;
@@ -1647,23 +1654,25 @@ static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stre
     return launch_kernel(sage_attn_kernel<D, false, false, false, true, 1, MASK>, C::LDS_BYTES, p, nwork, stream);
 }
 
-template <int D, bool CAUSAL, int QF>
+template <int D, bool PV_FP8, bool CAUSAL, int QF>
 static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t stream)
 {
-    using C = TileCfg<D, true, SAGE_NH_F8>;
-    return launch_kernel(sage_attn_kernel<D, true, CAUSAL, true, true, SAGE_NH_F8, 0, QF>, C::LDS_BYTES, p, nwork, stream);
+    // FP8 PV: two-level accumulation; FP16 PV: straight FP32 accumulation (the entry points' defaults); tile shapes as launch_attn
+    constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
+    using C = TileCfg<D, PV_FP8, NH>;
+    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
 }
 
-// FP8 PV, two-level accumulation, per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel
-hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream)
+// per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
+hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
 {
     const int nwork = p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
-#define SAGE_FQ(D_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, false, 1>(p, nwork, stream); \
-                         return causal ? launch_fused_q_one<D_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, false, 2>(p, nwork, stream); } while (0)
-    if (head_dim == 128) SAGE_FQ(128);
-    if (head_dim == 64) SAGE_FQ(64);
+#define SAGE_FQ(D_, F_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, F_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 1>(p, nwork, stream); \
+                             return causal ? launch_fused_q_one<D_, F_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 2>(p, nwork, stream); } while (0)
+    if (head_dim == 128) { if (pv_fp8) SAGE_FQ(128, true); else SAGE_FQ(128, false); }
+    if (head_dim == 64) { if (pv_fp8) SAGE_FQ(64, true); else SAGE_FQ(64, false); }
 #undef SAGE_FQ
     return hipErrorInvalidValue;
 }

@@ -375,9 +375,9 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
                           int B, int Hq, int Hkv, int Lq, int Lk, int D,
                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                          int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream)
+                          int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream, bool pv_fp8 = true)
 {
-    SAGE_REQUIRE(q && k && v_image && o && k_scale && v_scale, "null tensor pointer");
+    SAGE_REQUIRE(q && k && v_image && o && k_scale && (v_scale || !pv_fp8), "null tensor pointer");
     SAGE_REQUIRE(kv_split >= 0 && (kv_split <= 1 || Hkv % kv_split == 0), "kv_split (%d) must divide the folded kv-head count (%d)", kv_split, Hkv);
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0 && Lk > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d Lk=%d)", B, Hq, Hkv, Lq, Lk);
@@ -403,7 +403,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = sm_scale_log2;
     p.kv_split = kv_split;
-    return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, static_cast<hipStream_t>(stream)),
+    return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, pv_fp8, static_cast<hipStream_t>(stream)),
                         "sage_attn_fused_q launch");
 }
 
@@ -416,6 +416,17 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
 {
     return fused_q_common(q, k, v_image, o, lse, k_scale, v_scale, v_mean, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
                           o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream);
+}
+
+SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
+                                      const float *k_scale, const float *v_mean,
+                                      int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                      int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+{
+    return fused_q_common(q, k, v_image, o, lse, k_scale, nullptr, v_mean, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, false);
 }
 
 SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,

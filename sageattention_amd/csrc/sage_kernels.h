@@ -44,8 +44,8 @@ struct AttnParams {
 // mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
                        bool two_level, int mask_kind, hipStream_t stream);
-// q in fp16 / bf16, quantised per-thread in the kernel prologue; FP8 PV, two-level accumulation, dense only
-hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream);
+// q in fp16 / bf16, quantised per-thread in the kernel prologue; dense only.  FP8 PV: two-level accumulation; FP16 PV: FP32 accumulation
+hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream);
 
 // ---- INT8 quantisation of Q / K ----------------------------------------------------------------
 enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style

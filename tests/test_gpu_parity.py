@@ -549,7 +549,12 @@ def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
     # rounding has a fixed quantum (2^-24 for fp16), so round(2x) may differ from 2*round(x) by one
     tiny = 2.0 ** -13 if o.dtype == torch.float16 else 2.0 ** -120
     normal = o.abs() >= tiny
-    assert torch.equal(o2[normal], (o * 2)[normal]), "V -> 2V must double the output bit-exactly"
+    bad = (o2 != o * 2) & normal
+    if bool(bad.any()):       # say where: a race shows up as whole rows / tiles, a rounding issue as scattered single elements
+        idx = bad.nonzero()
+        where = {f"dim{d}": (int(idx[:, d].min()), int(idx[:, d].max()), int(idx[:, d].unique().numel())) for d in range(idx.size(1))}
+        raise AssertionError(f"V -> 2V must double the output bit-exactly: {int(bad.sum())} elements differ, index ranges (min, max, distinct) {where}, "
+                             f"first {idx[0].tolist()}: {o2[tuple(idx[0])].item()} vs {2 * o[tuple(idx[0])].item()}, nan={bool(o2.isnan().any())}/{bool(o.isnan().any())}")
     assert (o2.float() - 2 * o.float()).abs().max().item() <= 2.0 ** -23
     # (2) batch*head shard invariance: a slice of the heads gives the same bits (multi-GPU sharding)
     hs = slice(q.size(1) // 2, q.size(1) // 2 + 4)

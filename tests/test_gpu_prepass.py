@@ -191,3 +191,47 @@ def test_head_barrier_makes_progress_while_other_kernels_hold_the_chip():
         for a, b, name in zip(got2, ref2, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, name + " (64-slab heads, side stream)")
     assert _sync_flags() == 0
+
+
+@pytest.mark.parametrize("D,causal,layout,dtype,pv_accum,smooth_v,gqa", [
+    (128, True, "HND", torch.bfloat16, "fp32", False, 1),
+    (128, False, "NHD", torch.float16, "fp32", False, 4),
+    (64, True, "HND", torch.float16, "fp32", False, 1),
+    (64, False, "HND", torch.bfloat16, "fp16", True, 2),          # sub_mean + v_mean epilogue
+    (128, True, "HND", torch.float16, "fp16", True, 1),
+])
+def test_fp16_pv_fused_q_is_bit_equal(D, causal, layout, dtype, pv_accum, smooth_v, gqa):
+    """sageattn_qk_int8_pv_fp16_cuda quantises Q inside the attention kernel by default: same bits as the separate quantiser."""
+    import warnings
+    import sageattention_amd as sa
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Hq, Hkv, Lq, Lk = 8, 8 // gqa, 1111, 1500
+    mk = lambda h, l: (torch.randn((2, h, l, D) if layout == "HND" else (2, l, h, D), device="cuda", dtype=torch.float32, generator=g)).to(dtype)
+    q, k, v = mk(Hq, Lq if not causal else Lk), mk(Hkv, Lk), mk(Hkv, Lk)
+    kw = dict(tensor_layout=layout, is_causal=causal, qk_quant_gran="per_thread", pv_accum_dtype=pv_accum, smooth_v=smooth_v, return_lse=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o0, l0 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, fuse_q_quant=False, **kw)
+        o1, l1 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, **kw)
+    _same(o1, o0, "o")
+    _same(l1, l0, "lse")
+
+
+def test_fp16_pv_kernel_is_repeatable_between_other_kernels():
+    """Two identical FP16-PV calls must give identical bits whatever ran in between (guards the drain of the pipelined loop:
+    its LDS-DMA once overwrote V fragments a slower wave was still reading, profiles/r2_run_r3l_fp16_drain_race.txt)."""
+    import sageattention_amd as sa
+    g = torch.Generator(device="cuda").manual_seed(9)
+    q, k, v = (torch.randn(2, 32, 4096, 128, device="cuda", dtype=torch.float32, generator=g).to(torch.float16) for _ in range(3))
+    v = torch.where(v.abs() < 2.0 ** -12, torch.full_like(v, 2.0 ** -12), v)
+    x = torch.randn(4, 8, 777, 64, device="cuda", dtype=torch.bfloat16, generator=g)
+    ref = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True, smooth_k=False)
+    for rep in range(12):
+        if rep % 3 == 0:
+            sa.sageattn(x, x, x, is_causal=bool(rep & 1))
+        elif rep % 3 == 1:
+            quant.prepass_kv_fp8(x, x, "HND", smooth_k=True, smooth_v=True)
+        o = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True, smooth_k=False)
+        o2 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v * 2, is_causal=True, smooth_k=False)
+        _same(o, ref, f"repeat {rep}")
+        assert torch.equal(o2, ref * 2), f"V -> 2V, repeat {rep}"
