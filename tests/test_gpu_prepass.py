@@ -234,4 +234,6 @@ def test_fp16_pv_kernel_is_repeatable_between_other_kernels():
         o = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True, smooth_k=False)
         o2 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v * 2, is_causal=True, smooth_k=False)
         _same(o, ref, f"repeat {rep}")
-        assert torch.equal(o2, ref * 2), f"V -> 2V, repeat {rep}"
+        normal = ref.abs() >= 2.0 ** -13            # in the fp16 subnormal range round(2x) may differ from 2 round(x) by one quantum
+        bad = (o2 != ref * 2) & normal
+        assert not bool(bad.any()), f"V -> 2V, repeat {rep}: {int(bad.sum())} elements, first {bad.nonzero()[0].tolist()}"
