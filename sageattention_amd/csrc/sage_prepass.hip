@@ -25,6 +25,9 @@
 #include "sage_quant_math.h"
 #include <type_traits>
 
+#ifndef SAGE_PP_RELEASE
+#define SAGE_PP_RELEASE 0  // experiment: 1 = the arrival is an agent-scope RELEASE (adds one buffer_wbl2 per workgroup)
+#endif
 #ifndef SAGE_PP_TRACE
 #define SAGE_PP_TRACE 0    // experiment: thread 0 of every workgroup appends 100 MHz time stamps behind the used part of ws
 #endif
@@ -207,7 +210,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(cnt, 1u, SAGE_PP_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // bounded (about a second): if the forward-progress assumption above were ever violated the launch would
                 // finish with wrong numbers and a sticky flag in the head's sync line instead of hanging the device
                 unsigned polls = 0;
