@@ -237,3 +237,43 @@ def test_fp16_pv_kernel_is_repeatable_between_other_kernels():
         normal = ref.abs() >= 2.0 ** -13            # in the fp16 subnormal range round(2x) may differ from 2 round(x) by one quantum
         bad = (o2 != ref * 2) & normal
         assert not bool(bad.any()), f"V -> 2V, repeat {rep}: {int(bad.sum())} elements, first {bad.nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("dt,D,layout,L,gran,blkk,smooth_v", [
+    (0, 128, "HND", 1500, "per_thread", 64, False),
+    (1, 64, "NHD", 700, "per_warp", 64, True),
+    (1, 128, "HND", 2100, "per_thread", 128, True),
+    (0, 64, "HND", 129, "per_warp", 128, False),
+])
+def test_fused_prepass_vs_oracle(oracle_mod, dt, D, layout, L, gran, blkk, smooth_v):
+    """The one-launch kernel against the CPU oracle directly (oracle quantisers fed the kernel's own K mean / V mean, which are
+    checked against the fp32 means): INT8 K, K scales, V scales and FP8 bytes bit-exact, padding tokens zero."""
+    import numpy as np
+    import util
+    O = oracle_mod
+    dtype = torch.float16 if dt == 0 else torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    B, H = 2, 3
+    k = (torch.randn(B, H, L, D, generator=g) + 2.0 * torch.randn(1, H, 1, D, generator=g)).to(dtype)
+    v = (torch.randn(B, H, L, D, generator=g) * (1 + 3 * torch.rand(1, H, 1, D, generator=g)) + 1.5).to(dtype)
+    dev = lambda t: t.cuda() if layout == "HND" else t.cuda().transpose(1, 2).contiguous()
+    hnd = lambda t: t if layout == "HND" else t.transpose(1, 2)
+    km, k8, ks, vimg, vs, vm = quant.prepass_kv_fp8(dev(k), dev(v), layout, smooth_k=True, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran)
+    torch.cuda.synchronize()
+    # K mean: fp32 mean rounded once to the input dtype (half an ulp of slack for the summation order)
+    want_km = k.double().mean(dim=2)
+    ulp = 2.0 ** -10 if dt == 0 else 2.0 ** -7
+    assert ((km.cpu().double() - want_km).abs() <= 0.51 * ulp * want_km.abs().clamp_min(2.0 ** -14) + 1e-7).all()
+    style = O.STYLE_TRITON_THREAD if gran == "per_thread" else O.STYLE_CUDA
+    gk, nk = O.group_index(L, gran, "k", blkk, blkk)
+    rk8, rks = O.quant_int8(util.bits(k), dt, gk, nk, style=style, mean=util.bits(km.cpu()))
+    assert (hnd(k8).cpu().numpy() == rk8).all() and (ks.cpu().numpy() == rks).all()
+    mean = None
+    if smooth_v:
+        want_vm = O.v_mean_padded16(util.bits(v), dt)
+        assert np.abs(vm.cpu().numpy() - want_vm).max() <= 1e-5 * max(1.0, float(np.abs(want_vm).max()))
+        mean = vm.cpu().numpy()
+    r8, rvs = O.quant_v_fp8(util.bits(v), dt, mean=mean)
+    assert (vs.cpu().numpy() == rvs).all()
+    assert (util.decode_v_image(vimg.cpu().numpy(), L, fp8=True) == r8).all()
+    assert (util.decode_v_image(vimg.cpu().numpy(), vimg.shape[2] * 64, fp8=True)[..., L:, :] == 0).all()
