@@ -104,7 +104,7 @@ prep_v_kernel(const PrepVParams p)
                 word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
                 pk[w] = (unsigned)word;
             }
-            *reinterpret_cast<v4u *>(out + d * 64 + pc * 16) = pk;
+            __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(out + d * 64 + pc * 16));
         }
     } else {
         unsigned char *out = reinterpret_cast<unsigned char *>(p.out) + tile_idx * (long)(D * 128);
@@ -129,7 +129,7 @@ prep_v_kernel(const PrepVParams p)
                 }
                 pk[w] = word;
             }
-            *reinterpret_cast<v4u *>(out + d * 128 + pc * 16) = pk;
+            __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(out + d * 128 + pc * 16));
         }
     }
 }

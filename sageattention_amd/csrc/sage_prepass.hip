@@ -28,6 +28,10 @@
 #ifndef SAGE_PP_RELEASE
 #define SAGE_PP_RELEASE 0  // experiment: 1 = the arrival is an agent-scope RELEASE (adds one buffer_wbl2 per workgroup)
 #endif
+#ifndef SAGE_PP_NT
+#define SAGE_PP_NT 1       // non-temporal stores of the INT8 / FP8 output: 123 -> 99 us at C3 (they no longer push the
+                           // slabs other workgroups are about to read out of the L2); 0 = ordinary stores
+#endif
 #ifndef SAGE_PP_TRACE
 #define SAGE_PP_TRACE 0    // experiment: thread 0 of every workgroup appends 100 MHz time stamps behind the used part of ws
 #endif
@@ -411,7 +415,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                         if constexpr (STYLE == 0) q[j] = quant_round_cuda(f[j], y);
                         else q[j] = quant_round_triton_nz(f[j], sc, y);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(pack_int8x4(q[0], q[1], q[2], q[3]), orsrc, orun, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pack_int8x4(q[0], q[1], q[2], q[3]), orsrc, orun, 0, SAGE_PP_NT ? 2 : 0);
                     orun += ostep;
                     asm volatile("" : "+v"(orun) :: "memory");
                 }
@@ -464,7 +468,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                         word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
                         pk[w] = (unsigned)word;
                     }
-                    *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
+                    if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16));
+                    else *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
                 }
                 __syncthreads();
             }

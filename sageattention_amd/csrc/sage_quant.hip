@@ -127,7 +127,7 @@ quant_int8_kernel(const QuantParams p)
         v4u pk;
 #pragma unroll
         for (int w = 0; w < 4; w++) pk[w] = pack_int8x4(q[4 * w], q[4 * w + 1], q[4 * w + 2], q[4 * w + 3]);
-        *reinterpret_cast<v4u *>(p.out + ooff + (long)row * p.o_sl + col) = pk;
+        __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(p.out + ooff + (long)row * p.o_sl + col));   // written once, read by a later kernel
     }
 }
 
