@@ -4,9 +4,9 @@
 //   K: stats_partial + stats_final (k.mean(dim=seq), core.py:280) + quant_int8_kernel (fused.cu:64-198 /
 //      quant_per_thread.py:58-98 with the `k - km` of core.py:281 fused)                       3 launches, 4 B/elt read
 //   V: stats_partial + stats_final + prep_v_kernel (fused.cu:262-427, quant.py:224-293)         3 launches, 4 B/elt read
-// A workgroup owns one 512-token slab of one (batch, kv-head) of K or of V and keeps it in REGISTERS (32 x 16 B per
-// thread at D = 128) across the three steps
-//   1. per-channel (max, min, sum) of the slab -> workspace          (same summation order as sage_stats.hip)
+// A 512-thread workgroup owns one 512-token slab of one (batch, kv-head) of K or of V and keeps it in REGISTERS (32 rows x
+// 8 B per thread at D = 128) across the three steps
+//   1. per-channel statistics of the slab -> workspace: sums for K, (max, min, sum) for V   (summation order of sage_stats.hip)
 //   2. wait until the other slabs of the head have published theirs; reduce them in slab order
 //   3. quantise the slab from the registers: INT8 rows + group scales (K), FP8 PV-operand tile image (V)
 // so HBM sees 2 B/elt in and 1 B/elt out -- the algorithmic minimum -- instead of 4 + 1.
@@ -14,7 +14,8 @@
 // Step 2 is a per-head barrier between workgroups of one launch.  It is safe because (a) gfx950 hands workgroups to
 // its 8 XCDs round-robin and each XCD starts its share in index order, (b) the slabs of a head are consecutive in
 // index, so the lowest unfinished head always has every slab resident or next in line, and (c) the C ABI refuses
-// heads of more than kPrepassMaxSlabs slabs (8 per XCD), far below the resident-workgroup capacity (2 per CU).
+// heads of more than kPrepassMaxSlabs slabs (8 per XCD) or than the device has CUs, far below the resident-workgroup
+// capacity (2 per CU).
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.
 // The two counters of a head return to zero before the kernel ends, so one zero-initialised sync buffer serves every
@@ -29,8 +30,8 @@
 #define SAGE_PP_RELEASE 0  // experiment: 1 = the arrival is an agent-scope RELEASE (adds one buffer_wbl2 per workgroup)
 #endif
 #ifndef SAGE_PP_NT
-#define SAGE_PP_NT 1       // non-temporal stores of the INT8 / FP8 output: 123 -> 99 us at C3 (they no longer push the
-                           // slabs other workgroups are about to read out of the L2); 0 = ordinary stores
+#define SAGE_PP_NT 1       // non-temporal stores of the INT8 / FP8 output (written once, read by a later kernel): 123 -> 99 us
+                           // at C3 in back-to-back launches, neutral inside sageattn(); 0 = ordinary stores
 #endif
 #ifndef SAGE_PP_TRACE
 #define SAGE_PP_TRACE 0    // experiment: thread 0 of every workgroup appends 100 MHz time stamps behind the used part of ws
