@@ -38,3 +38,20 @@ def test_prepass_kernel_keeps_its_slab_in_registers():
     for name, res in kernels.items():
         assert res["VGPRs Spill"] == 0 and res["ScratchSize"] == 0, (name, res)
         assert res["VGPRs"] <= 128 and res["Occupancy"] >= 4, (name, res)        # two 512-thread workgroups per CU
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_attention_kernels_do_not_spill():
+    """The pipelined attention loops pin their instruction order with inline asm and sit a few registers below the occupancy
+    limits (D = 128 FP8: 2 waves / SIMD at <= 256 VGPRs; D = 64: 3 waves at <= 168): a spill there would not fail any
+    numerical test, only the benchmark."""
+    kernels = {k: v for k, v in _resource_report("sage_attn.hip").items() if "sage_attn_kernel" in k}
+    assert len(kernels) >= 40, len(kernels)
+    spilled = {k: v for k, v in kernels.items() if v["VGPRs Spill"] > 0}
+    # one general-path-only instantiation (D = 64, FP16 PV, per-thread K, single-level) spills a single register in its
+    # masked tail iteration; everything on a benchmark path must be clean
+    assert len(spilled) <= 1 and all(v["VGPRs Spill"] <= 2 for v in spilled.values()), spilled
+    head = [v for k, v in kernels.items() if "ILi128ELb1ELb1ELb1ELb1E" in k]          # D=128, FP8 PV, causal, per-thread, two-level
+    assert head and all(v["VGPRs Spill"] == 0 and v["Occupancy"] >= 2 for v in head), head
+    d64 = [v for k, v in kernels.items() if "ILi64ELb1E" in k]                        # D=64, FP8 PV
+    assert d64 and all(v["VGPRs Spill"] == 0 and v["Occupancy"] >= 3 for v in d64), d64
