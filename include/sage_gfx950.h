@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 8
+#define SAGE_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -135,7 +135,8 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *   K: km = k.mean(dim=seq) (core.py:280) -> k_mean [B,H,D] (input dtype), INT8 (k - km) + group scales as
  *      sage_quant_qk_int8 writes them for is_key = 1, blk = warp = k_blk, qk_quant_gran per-block or per-thread;
  *      k_mean == NULL: no smoothing (smooth_k = False)
- *   V: v_image / v_scale / v_mean exactly as sage_prep_v_fp8 (v_mean != NULL => smooth_v)
+ *   V: v_image / v_scale / v_mean exactly as sage_prep_v_fp8 (v_mean != NULL => smooth_v); v_fp16 != 0: the fp16 image of
+ *      sage_prep_v_f16 instead (`v.to(float16)`, core.py:297-298,613; no statistics, v_scale / v_mean unused)
  * Either of k / v may be NULL to run one half.  Results are bit-identical to the sage_channel_mean +
  * sage_quant_qk_int8 + sage_prep_v_fp8 sequence (6 launches, 4 B/elt read): same per-slab summation order.
  *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
@@ -155,7 +156,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
                     int B, int H, int L, int D,
                     int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
-                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int dtype, void *stream);
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, void *stream);
 
 /* V pre-pass, FP16: (bf16 -> fp16) + transpose into the tile image.  Replaces `v.to(float16)`
  * (core.py:297-298,613) and, with v_mean != NULL ([B,H,D] fp32 to subtract), sub_mean_cuda

@@ -349,12 +349,13 @@ def _fused_prepass_wanted(k, tensor_layout: str, override: Optional[bool]) -> bo
     return L > 256 or B * H <= 256
 
 
-def _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, blkk, smooth_k, smooth_v, return_lse, fused: bool, v_fp8: bool = True):
+def _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, blkk, smooth_k, smooth_v, return_lse, fused: bool, v_fp8: bool = True,
+                v_fp16: bool = False):
     """K mean + INT8 K (+ FP8 V image when ``v_fp8``).  Returns (lse_correction, km [B,H,D] | None, k_int8, k_scale, v_image,
     v_scale, vm); the K conventions are those of ``per_thread_int8`` / ``per_warp_int8`` / ``per_block_int8(cuda)``."""
     if fused:
-        km_s, k_int8, k_scale, v_image, v_scale, vm = prepass_kv_fp8(k, v if v_fp8 else None, tensor_layout, smooth_k=smooth_k,
-                                                                     smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=qk_quant_gran)
+        km_s, k_int8, k_scale, v_image, v_scale, vm = prepass_kv_fp8(k, v if (v_fp8 or v_fp16) else None, tensor_layout, smooth_k=smooth_k,
+                                                                     smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=qk_quant_gran, v_fp16=v_fp16)
         lse_correction = None
         if smooth_k and return_lse:
             lse_correction = _lse_correction(q, km_s.unsqueeze(1 if tensor_layout == "NHD" else 2), tensor_layout)
@@ -395,13 +396,14 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
         smooth_v = False
     warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32") else 32              # core.py:602-604
     fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass"))
-    lse_correction, _, k_int8, k_scale, _, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
-                                                              fused, v_fp8=False)
+    v_in_prepass = fused and not smooth_v and k.shape == v.shape          # the fp16 image comes out of the same launch as K
+    lse_correction, _, k_int8, k_scale, v_image, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
+                                                                    fused, v_fp8=False, v_fp16=v_in_prepass)
     vm = None
     if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
         v_image, vm = sub_mean(v, tensor_layout)
         vm = vm.float()
-    else:
+    elif not v_in_prepass:
         v_image = prep_v_fp16(v, tensor_layout)
     if qk_quant_gran == "per_thread" and pv_accum_dtype != "fp16+fp32" and kwargs.get("fuse_q_quant", _FUSE_Q16_DEFAULT):
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM, one launch less)

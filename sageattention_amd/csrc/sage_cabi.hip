@@ -264,7 +264,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
                     int B, int H, int L, int D,
                     int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
-                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int dtype, void *stream)
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, void *stream)
 {
     SAGE_REQUIRE(k || v, "nothing to do: both k and v are null");
     SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its (zeroed) sync buffer");
@@ -288,17 +288,18 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         else return fail(SAGE_EINVAL, "bad k granularity %d (per-block or per-thread)", qk_quant_gran);
     }
     if (v) {
-        SAGE_REQUIRE(v_image && v_scale, "V part needs v_image and v_scale");
+        SAGE_REQUIRE(v_image && (v_scale || v_fp16), "V part needs v_image (and v_scale for the FP8 image)");
         SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
         SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "input strides must be multiples of 8 elements");
-        SAGE_REQUIRE(scale_max > 0.0f, "scale_max must be positive");
+        SAGE_REQUIRE(v_fp16 || scale_max > 0.0f, "scale_max must be positive");
+        SAGE_REQUIRE(!(v_fp16 && v_mean), "the fp16 image has no smooth_v (use sage_prep_v_f16 with a mean for sub_mean)");
     }
     p.k = k; p.v = v; p.k_mean = k_mean; p.k_out = k_int8; p.k_scale = k_scale;
     p.v_image = v_image; p.v_scale = v_scale; p.v_mean = v_mean; p.ws = ws; p.sync = sync;
     p.B = B; p.H = H; p.L = L; p.D = D; p.nslab = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
     p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
     p.ko_sb = ko_sb; p.ko_sh = ko_sh; p.ko_sl = ko_sl;
-    p.k_blk = k_blk; p.k_warp = k_blk; p.k_style = k_style; p.dtype = dtype; p.scale_max = scale_max;
+    p.k_blk = k_blk; p.k_warp = k_blk; p.k_style = k_style; p.dtype = dtype; p.scale_max = scale_max; p.v_fp16 = v_fp16 ? 1 : 0;
     return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv launch");
 }
 

@@ -113,7 +113,7 @@ struct PrepassParams {
     void *k_mean;             // nullable [B,H,D] out, input dtype; non-null = smooth_k (subtract it before quantising)
     int8_t *k_out;            // INT8 K, strides ko_*
     float *k_scale;           // [B,H,ceil(L/k_blk)*groups]
-    void *v_image;            // fp8 tile image [B,H,ceil(L/64),D,64]
+    void *v_image;            // tile image [B,H,ceil(L/64),D,64], fp8 or fp16 (v_fp16)
     float *v_scale;           // [B,H,D] out
     float *v_mean;            // nullable [B,H,D] out; non-null = smooth_v
     float *ws;                // [2,B,H,nslab,3,D] slab partials
@@ -123,6 +123,7 @@ struct PrepassParams {
     long v_sb, v_sh, v_sl;
     long ko_sb, ko_sh, ko_sl;
     int parts;                // 1: K only, 2: V only, 3: both
+    int v_fp16;               // V half: 0 = per-channel FP8 image (statistics + scales), 1 = fp16 image (`v.to(float16)`, no statistics)
     int k_blk;                // keys per scale block: 64 / 128
     int k_warp;               // == k_blk (one thread-group map per block)
     int k_gran;               // GR_BLOCK / GR_THREAD_K

@@ -162,7 +162,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     SAGE_STAMP();                                  // 1: slab loaded
 #endif
 
-    const bool need_stats = is_v || p.k_mean != nullptr;
+    const bool need_stats = IS_V ? (p.v_fp16 == 0) : (p.k_mean != nullptr);      // the fp16 image needs no statistics, no barrier
     if (need_stats) {
         // ---- 1. slab statistics, rows in index order (bit-compatible with stats_partial_kernel) ----------------------
         float mx[4], mn[4], sm[4];
@@ -231,10 +231,11 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             // slabs in index order; sixteen slabs' loads are in flight together (one round trip to the coherence point per batch,
             // not one per slab: with the loads issued one by one this loop alone cost ~2 us x nslab per workgroup)
             float a = -INFINITY, c = INFINITY, s = 0.0f;
-            for (int i0 = 0; i0 < p.nslab; i0 += 16) {
-                float va[16], vc[16], vs[16];
+            constexpr int NB = (D == 128) ? 16 : 8;       // slabs per batch of loads (D = 64: 8 keeps the kernel at 3 workgroups per CU)
+            for (int i0 = 0; i0 < p.nslab; i0 += NB) {
+                float va[NB], vc[NB], vs[NB];
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < NB; u++) {
                     const float *wi = ws + (long)min(i0 + u, p.nslab - 1) * 3 * D;
                     if constexpr (IS_V) {
                         va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -243,7 +244,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     vs[u] = __hip_atomic_load(wi + 2 * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < NB; u++) {
                     if (i0 + u < p.nslab) {
                         if constexpr (IS_V) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); }
                         s += vs[u];
@@ -429,50 +430,91 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         if (p.k_style == QS_CUDA) by_smooth(std::integral_constant<int, 0>{});
         else by_smooth(std::integral_constant<int, 1>{});          // QS_TRITON_THREAD (checked by the C ABI)
     } else {
-        // ---- 3b. V: FP8 tile image, two 64-token tiles per LDS stage (the arithmetic of prep_v_kernel) -------------------
+        // ---- 3b. V: tile image, two 64-token tiles per LDS stage (the arithmetic of prep_v_kernel) ------------------------
         const bool smooth = p.v_mean != nullptr;
         const int ntiles = (L + BLKK - 1) / BLKK;
-        unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 64);
         constexpr int RPS = 2 * BLKK / RPI;                 // rows of a thread per stage
+        auto stage_in = [&](int s) {                        // the stage's 128 rows -> LDS
 #pragma unroll
-        for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
-            if (row0 + s * 2 * BLKK < L) {                  // workgroup-uniform
+            for (int m = 0; m < RPS; m++) {
+                const int rs = r0 + m * RPI;                // row inside the stage (0..127)
+                const v2u t = {rw[s * RPS + m][0], rw[s * RPS + m][1]};
+                *reinterpret_cast<v2u *>(&tile[rs >> 6][(rs & 63) * LDT + c4]) = t;
+            }
+        };
+        if (p.v_fp16 == 0) {
+            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 64);
 #pragma unroll
-                for (int m = 0; m < RPS; m++) {
-                    const int rs = r0 + m * RPI;            // row inside the stage (0..127)
-                    const v2u t = {rw[s * RPS + m][0], rw[s * RPS + m][1]};
-                    *reinterpret_cast<v2u *>(&tile[rs >> 6][(rs & 63) * LDT + c4]) = t;
-                }
-                __syncthreads();
+            for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
+                if (row0 + s * 2 * BLKK < L) {                  // workgroup-uniform
+                    stage_in(s);
+                    __syncthreads();
 #pragma unroll
-                for (int it = 0; it < 2 * D * 4 / NT; it++) {
-                    const int piece = tid + NT * it;
-                    const int tt = piece / (D * 4), pin = piece % (D * 4);
-                    const int d = pin >> 2, pc = pin & 3;
-                    const int t = (row0 >> 6) + 2 * s + tt;
-                    if (t >= ntiles) continue;
-                    const int ch = swz_chunk<64>(d, pc);
-                    const float mean = ch_mean[d], recp = ch_recp[d];
-                    float f[16];
+                    for (int it = 0; it < 2 * D * 4 / NT; it++) {
+                        const int piece = tid + NT * it;
+                        const int tt = piece / (D * 4), pin = piece % (D * 4);
+                        const int d = pin >> 2, pc = pin & 3;
+                        const int t = (row0 >> 6) + 2 * s + tt;
+                        if (t >= ntiles) continue;
+                        const int ch = swz_chunk<64>(d, pc);
+                        const float mean = ch_mean[d], recp = ch_recp[d];
+                        float f[16];
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int tok = pv_token_of_position(16 * ch + j);
-                        float xv = ld16<DT>(tile[tt][tok * LDT + d]);
-                        if (smooth) xv = (t * BLKK + tok < L) ? xv - mean : 0.0f;      // padding stays zero
-                        xv *= recp;
-                        f[j] = fminf(fmaxf(xv, -448.0f), 448.0f);                      // satfinite
+                        for (int j = 0; j < 16; j++) {
+                            const int tok = pv_token_of_position(16 * ch + j);
+                            float xv = ld16<DT>(tile[tt][tok * LDT + d]);
+                            if (smooth) xv = (t * BLKK + tok < L) ? xv - mean : 0.0f;      // padding stays zero
+                            xv *= recp;
+                            f[j] = fminf(fmaxf(xv, -448.0f), 448.0f);                      // satfinite
+                        }
+                        v4u pk;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
+                            word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
+                            pk[w] = (unsigned)word;
+                        }
+                        if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16));
+                        else *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
                     }
-                    v4u pk;
-#pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
-                        word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
-                        pk[w] = (unsigned)word;
-                    }
-                    if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16));
-                    else *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
+                    __syncthreads();
                 }
-                __syncthreads();
+            }
+        } else {
+            // FP16-PV entry points: `v.to(float16)` (core.py:297-298,613) as the fp16 tile image of prep_v_kernel -- no
+            // statistics, no barrier: load, transpose through LDS, store
+            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 128);
+#pragma unroll
+            for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
+                if (row0 + s * 2 * BLKK < L) {
+                    stage_in(s);
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < 2 * D * 8 / NT; it++) {
+                        const int piece = tid + NT * it;
+                        const int tt = piece / (D * 8), pin = piece % (D * 8);
+                        const int d = pin >> 3, pc = pin & 7;
+                        const int t = (row0 >> 6) + 2 * s + tt;
+                        if (t >= ntiles) continue;
+                        const int ch = swz_chunk<128>(d, pc);
+                        v4u pk;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            unsigned word = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                const int tok = pv_token_of_position(8 * ch + 2 * w + e);
+                                uint16_t raw = tile[tt][tok * LDT + d];
+                                if (DT != DT_F16) raw = f32_to_f16_rne(bf16_to_f32(raw));
+                                word |= (unsigned)raw << (16 * e);
+                            }
+                            pk[w] = word;
+                        }
+                        if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 128) + d * 128 + pc * 16));
+                        else *reinterpret_cast<v4u *>(img + (long)t * (D * 128) + d * 128 + pc * 16) = pk;
+                    }
+                    __syncthreads();
+                }
             }
         }
     }

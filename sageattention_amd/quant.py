@@ -245,13 +245,15 @@ def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
 
 @_eager
 def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: str = "HND", smooth_k: bool = True,
-                   smooth_v: bool = False, BLKK: int = 64, qk_quant_gran: str = "per_thread", scale_max: float = 448.0):
+                   smooth_v: bool = False, BLKK: int = 64, qk_quant_gran: str = "per_thread", scale_max: float = 448.0,
+                   v_fp16: bool = False):
     """K and V pre-pass of the FP8-PV entry points in ONE launch that reads K and V once: the bits of
     ``channel_mean`` + ``per_thread_int8`` / ``per_warp_int8`` (K side) + ``per_channel_fp8``.
     Returns ``(km [B,H,D] | None, k_int8, k_scale, v_image, v_scale, vm)``; ``v=None`` runs the K half only
     (``v_image, v_scale, vm`` are None).  ``qk_quant_gran`` "per_thread" gives 4 k scales per BLKK keys with the
     Triton-per-thread rounding, "per_warp" / "per_block" one scale per BLKK keys with the CUDA rounding
-    (quant.py:105-180) -- the K conventions of the reference's CUDA entry points."""
+    (quant.py:105-180) -- the K conventions of the reference's CUDA entry points.  ``v_fp16=True`` (FP16-PV entry points) makes
+    the V half the fp16 tile image of ``prep_v_fp16`` instead (``v_scale`` and ``vm`` are then None)."""
     k = _aligned(k, 8)
     B, H, L, D, k_sb, k_sh, k_sl = _dims(k, tensor_layout)
     dev = k.device
@@ -271,15 +273,19 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
         v = _aligned(v, 8)
         assert _dims(v, tensor_layout)[:4] == (B, H, L, D) and v.dtype == k.dtype, "k and v must have one shape and dtype"
         _, _, _, _, v_sb, v_sh, v_sl = _dims(v, tensor_layout)
-        v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.uint8, device=dev)
-        v_scale = torch.empty((B, H, D), dtype=torch.float32, device=dev)
-        vm = torch.empty((B, H, D), dtype=torch.float32, device=dev) if smooth_v else None
+        if v_fp16:
+            assert not smooth_v, "the fp16 image has no smooth_v here (sub_mean goes through prep_v_fp16)"
+            v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.float16, device=dev)
+        else:
+            v_image = torch.empty((B, H, (L + 63) // 64, D, 64), dtype=torch.uint8, device=dev)
+            v_scale = torch.empty((B, H, D), dtype=torch.float32, device=dev)
+            vm = torch.empty((B, H, D), dtype=torch.float32, device=dev) if smooth_v else None
     lib = _cabi.load()
     ws = torch.empty((int(lib.sage_prepass_ws_floats(B, H, L, D)),), dtype=torch.float32, device=dev)
     sync = _prepass_sync(B, H, dev)
     rc = lib.sage_prepass_kv(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(v_scale), _p(vm), _p(ws), _p(sync),
                              B, H, L, D, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, ob, oh, ol,
-                             BLKK, gran, style, float(scale_max), _dtype_code(k), _stream(k))
+                             BLKK, gran, style, float(scale_max), int(bool(v_fp16)), _dtype_code(k), _stream(k))
     _cabi.check(rc, "sage_prepass_kv")
     return km, k_int8, k_scale, v_image, v_scale, vm
 

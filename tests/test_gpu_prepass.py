@@ -277,3 +277,19 @@ def test_fused_prepass_vs_oracle(oracle_mod, dt, D, layout, L, gran, blkk, smoot
     assert (vs.cpu().numpy() == rvs).all()
     assert (util.decode_v_image(vimg.cpu().numpy(), L, fp8=True) == r8).all()
     assert (util.decode_v_image(vimg.cpu().numpy(), vimg.shape[2] * 64, fp8=True)[..., L:, :] == 0).all()
+
+
+@pytest.mark.parametrize("B,H,L,D,dtype,layout", [
+    (2, 4, 1024, 128, torch.bfloat16, "HND"), (1, 3, 1000, 128, torch.float16, "NHD"), (2, 2, 77, 64, torch.bfloat16, "HND"),
+    (1, 2, 2048 + 513, 64, torch.float16, "HND"), (1, 1, 4096, 128, torch.bfloat16, "NHD"),
+])
+def test_fused_prepass_fp16_image_bit_equals_prep_v_fp16(B, H, L, D, dtype, layout):
+    k, v = _mk(B, H, L, D, dtype, layout, 3 * L + D)
+    want_img = quant.prep_v_fp16(v, layout)
+    ref = _sequence(k, v, layout, True, False, 64, "per_thread")
+    for rep in range(2):
+        km, k8, ks, vimg, vs, vm = quant.prepass_kv_fp8(k, v, layout, smooth_k=True, v_fp16=True)
+        assert vs is None and vm is None
+        _same(vimg, want_img, f"fp16 image (call {rep})")
+        for a, b, name in zip((km, k8, ks), ref[:3], ("km", "k_int8", "k_scale")):
+            _same(a, b, name)
