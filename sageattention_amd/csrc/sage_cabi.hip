@@ -281,6 +281,8 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(aligned16(k) && aligned16(k_int8), "k / k_int8 must be 16-byte aligned");
         SAGE_REQUIRE(k_sl % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0, "input strides must be multiples of 8 elements");
         SAGE_REQUIRE(ko_sl % 16 == 0 && ko_sh % 16 == 0 && ko_sb % 16 == 0, "int8 output strides must be multiples of 16");
+        SAGE_REQUIRE(((int64_t)(L - 1) * k_sl + D) * 2 < (int64_t)1 << 32 && (int64_t)(L - 1) * ko_sl + D < (int64_t)1 << 32,
+                     "one head of k spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
         SAGE_REQUIRE(k_blk == 64 || k_blk == 128, "k_blk must be 64 or 128 (got %d)", k_blk);
         SAGE_REQUIRE(k_style == sage::QS_CUDA || k_style == sage::QS_TRITON_THREAD, "k_style must be the CUDA (1) or the per-thread Triton (2) convention (got %d)", k_style);
         if (qk_quant_gran == SAGE_GRAN_PER_BLOCK) p.k_gran = sage::GR_BLOCK;
@@ -291,6 +293,8 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(v_image && (v_scale || v_fp16), "V part needs v_image (and v_scale for the FP8 image)");
         SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
         SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "input strides must be multiples of 8 elements");
+        SAGE_REQUIRE(((int64_t)(L - 1) * v_sl + D) * 2 < (int64_t)1 << 32,
+                     "one head of v spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
         SAGE_REQUIRE(v_fp16 || scale_max > 0.0f, "scale_max must be positive");
         SAGE_REQUIRE(!(v_fp16 && v_mean), "the fp16 image has no smooth_v (use sage_prep_v_f16 with a mean for sub_mean)");
     }

@@ -240,7 +240,9 @@ def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
 
 def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
     """Whether the one-launch pre-pass covers this K / V length (the slabs of a head wait for each other in the launch)."""
-    return _dims(k, tensor_layout)[2] <= int(_cabi.load().sage_prepass_max_seqlen())
+    _, _, L, D, _, _, sl = _dims(k, tensor_layout)
+    # the kernel addresses one head with 32-bit buffer offsets (row stride x rows x 2 bytes)
+    return L <= int(_cabi.load().sage_prepass_max_seqlen()) and ((L - 1) * sl + D) * 2 < 2 ** 32
 
 
 @_eager
