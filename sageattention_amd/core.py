@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _cabi, ops
 from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
-                    per_channel_fp8, per_thread_int8, per_warp_int8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean)
+                    per_channel_fp8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
 _FUSE_Q16_DEFAULT = __import__("os").environ.get("SAGE_FUSE_Q16", "1") != "0"      # debugging switch
