@@ -104,3 +104,23 @@ def test_bench_rank_units_partition_the_global_problem():
             assert qs.shape == (1, (hi - lo) * (Hq // Hkv), L, D) and ks.shape == (1, hi - lo, L, D)
             seen_q.append(qs.reshape(-1, L, D)); seen_k.append(ks.reshape(-1, L, D))
         assert torch.equal(torch.cat(seen_q), q.reshape(-1, L, D)) and torch.equal(torch.cat(seen_k), k.reshape(-1, L, D))
+
+
+def test_prepass_route_choice(monkeypatch):
+    """Which pre-pass a dense call takes (core._fused_prepass_wanted): the one-launch kernel unless it cannot take the head
+    (too long for the in-launch barrier / no device) or very many heads of <= 256 keys would leave its 512-row slabs half empty."""
+    meta = lambda *s: torch.empty(*s, device="meta", dtype=torch.float16)
+    monkeypatch.setattr(core, "prepass_fused_ok", lambda k, layout="HND": core._dims(k, layout)[2] <= 32768)
+    want = core._fused_prepass_wanted
+    assert want(meta(2, 32, 8192, 128), "HND", None)
+    assert want(meta(2, 8192, 32, 128), "NHD", None)
+    assert want(meta(1, 4, 200, 64), "HND", None)              # few heads: one launch instead of six
+    assert want(meta(8, 32, 257, 64), "HND", None)
+    assert not want(meta(64, 16, 256, 64), "HND", None)        # 1024 half-empty slabs
+    assert not want(meta(1, 2, 40000, 64), "HND", None)        # beyond the barrier's reach ...
+    assert not want(meta(1, 2, 40000, 64), "HND", True)        # ... whatever the caller asks for
+    assert not want(meta(2, 32, 8192, 128), "HND", False)
+    assert want(meta(64, 16, 256, 64), "HND", True)
+    # without a GPU the C ABI reports a maximum head length of 0: never the fused route, never a crash
+    monkeypatch.undo()
+    assert not core.prepass_fused_ok(torch.empty(1, 1, 64, 64, dtype=torch.float16)) or torch.cuda.is_available()
