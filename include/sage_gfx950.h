@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 9
+#define SAGE_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -63,6 +63,14 @@ extern "C" {
 
 SAGE_API int sage_abi_version(void);
 SAGE_API const char *sage_last_error(void);
+
+/* Kernel route of the dense FP8-PV, head_dim 128 attention entry points (sage_attn_qk_int8_pv_f8, sage_attn_fused_q_pv_f8).
+ * -1 (default): by shape -- calls with more than 128 query rows per head run the 256-row workgroup kernel (one wave per SIMD,
+ * sage_attn64.hip), the rest the 128-row kernel; 0: always the 128-row kernel; 1: the 256-row kernel wherever it is eligible.
+ * Both kernels implement the same reference kernels (csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:46-704) with the same operand
+ * order; the switch exists for A/B measurements and tests.  Process-wide; initialised from the environment variable SAGE_ATTN64. */
+SAGE_API int sage_attn64_mode(void);
+SAGE_API void sage_set_attn64_mode(int mode);
 
 /* Size in bytes of the tiled V^T image for `n_kv_tiles_total` 64-token tiles (all batches, heads). */
 SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total);

@@ -268,7 +268,13 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  *            (tl.dot(..., out_dtype=fp16) as the CPU interpreter evaluates it:
  *            fp32 sum rounded once), added to the fp32 accumulator.
  * pv_mode 1: fp16 P, fp32 tile product, fp32 accumulator (sm80 "fp32",
- *            qk_int_sv_f16_cuda_sm80.cu:303-420 in spirit).
+ *            qk_int_sv_f16_cuda_sm80.cu:303-420 in spirit).  The softmax denominator is the FP32
+ *            sum of the fp16-ROUNDED P: the kernels are instantiated with
+ *            DenominatorAccumUnit = kTensorCore (qk_int_sv_f16_cuda_sm80.cu:814,989,1164,1348), i.e.
+ *            RS_32_to_16 first, then accumulate_d -> mma::rowsum_f16f16f32 on the packed halves
+ *            (qk_int_sv_f16_cuda_sm80.cu:313-320, attn_utils.cuh:529-545).  pv_mode 0 (Triton) and the
+ *            FP8 modes sum the un-rounded exponentials (attn_qk_int8_per_block.py:57-60,
+ *            qk_int_sv_f8_cuda_sm90.cu:317-318).
  * pv_mode 2: FP8 PV, exp offset 8.807 (attn_utils.cuh:30,377-389), P->e4m3
  *            (attn_utils.cuh:478-493), per-tile product started from zero and
  *            added to the fp32 accumulator = two-level accumulation
@@ -382,8 +388,8 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                             if (p[i][j] <= NEG_BIG) e = 0.0f;
                             else if (fused) e = exp2f(fmaf(dotf[j], ccj[j], -m_new));
                             else e = exp2f(p[i][j] - m_new);
-                            rs += e;
                             p[i][j] = fp8 ? orc_e4m3_2f(orc_f2e4m3(e)) : orc_h2f(orc_f2h(e));
+                            rs += (pv_mode == 1) ? p[i][j] : e;   /* sm80 CUDA kernels: tensor-core row sum of the fp16 P */
                         }
                         l[i] = l[i] * alpha + rs;
                         m[i] = m_new;

@@ -29,6 +29,7 @@
 #include "sage_kernels.h"
 #include "sage_quant_math.h"
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 // ---- build-time switches used for the A/B ladder in DESIGN.md ------------------------------------
@@ -71,6 +72,9 @@
 #endif
 #ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
 #define SAGE_ASMDMA 1   // M0 write per image, inst_offset for the second piece) instead of four builtins with 64-bit VGPR addresses
+#endif
+#ifndef SAGE_PLAIN_PV   // pipelined FP8 loop: v_mfma_f32_32x32x64_f8f6f4 instead of its block-scaled form with unit scales
+#define SAGE_PLAIN_PV 1
 #endif
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
@@ -996,7 +1000,11 @@ sage_attn_kernel(const AttnParams p)
 #else
 #define SAGE_NOPX "s_nop 1\n\t"
 #endif
+#if SAGE_PLAIN_PV    // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix (same products; 8 bytes and one VGPR less per MFMA)
+#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#else
 #define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
+#endif
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
 #define A_QK(acc, a, b)    asm volatile(SAGE_NOPX "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
@@ -1022,7 +1030,7 @@ sage_attn_kernel(const AttnParams p)
                 v8i vf[C::DT];                                                        // V fragments of the previous tile
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
-                const int e8m0 = 0x7f7f7f7f;     // unit block scales
+                [[maybe_unused]] const int e8m0 = 0x7f7f7f7f;     // unit block scales (SAGE_PLAIN_PV == 0)
 #if SAGE_ASMDMA
                 static_assert(KP / 4 == VP / 4 && (KP / 4 == 1 || KP / 4 == 2), "asm LDS-DMA: one or two pieces per wave and image");
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -1663,12 +1671,35 @@ static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t
     return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
 }
 
+// ---- route between the 128-row kernel family above and the 256-row one-wave-per-SIMD kernel (sage_attn64.hip) -------------
+static int g_attn64_mode = -2;       // -2: not read yet
+int attn64_mode()
+{
+    if (g_attn64_mode == -2) {
+        const char *e = getenv("SAGE_ATTN64");
+        g_attn64_mode = (e != nullptr && e[0] != 0) ? atoi(e) : -1;
+    }
+    return g_attn64_mode;
+}
+void set_attn64_mode(int mode) { g_attn64_mode = mode; }
+static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
+{
+    if (!pv_fp8 || head_dim != 128 || p.cu_q != nullptr || p.kv_split > 1) return false;
+    const int mode = attn64_mode();
+    if (mode == 0) return false;
+    if (mode >= 1) return true;
+    // auto: the 128-row kernel.  Measured (profiles/r3_attn64_*): with one wave per SIMD every LDS-DMA issue, fragment read,
+    // scalar instruction and barrier wait of the wave is exposed, and the 256-row kernel runs 12-17 % behind at every size
+    return false;
+}
+
 // per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
 hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
 {
     const int nwork = p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
+    if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, true, q_dtype == DT_F16 ? 1 : 2, stream);
 #define SAGE_FQ(D_, F_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, F_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 1>(p, nwork, stream); \
                              return causal ? launch_fused_q_one<D_, F_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 2>(p, nwork, stream); } while (0)
     if (head_dim == 128) { if (pv_fp8) SAGE_FQ(128, true); else SAGE_FQ(128, false); }
@@ -1691,6 +1722,7 @@ hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool caus
         return mask_kind == 1 ? launch_masked<64, 1>(p, nwork, stream)
              : mask_kind == 2 ? launch_masked<64, 2>(p, nwork, stream) : launch_masked<64, 3>(p, nwork, stream);
     }
+    if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, kthread, 0, stream);
     // keys per iteration: 128 where two workgroups still fit a CU's LDS, else 64
     if (head_dim == 128) return pv_fp8 ? launch_d<128, true, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream)
                                        : launch_d<128, false, 1>(p, nwork, causal, kthread, two_level, stream);

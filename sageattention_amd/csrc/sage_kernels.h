@@ -47,6 +47,14 @@ hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool caus
 // q in fp16 / bf16, quantised per-thread in the kernel prologue; dense only.  FP8 PV: two-level accumulation; FP16 PV: FP32 accumulation
 hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream);
 
+// FP8 PV, dense, unmasked, D = 128 in the one-wave-per-SIMD form (sage_attn64.hip): 256 query rows per workgroup, 64 per wave.
+// qf: 0 = INT8 q + q_scale (any granularity), 1 / 2 = fp16 / bf16 q quantised in the prologue (per-thread groups)
+hipError_t launch_attn64(const AttnParams &p, int head_dim, bool causal, bool kthread, int qf, hipStream_t stream);
+// route of the FP8 D = 128 dense calls: -1 auto (by shape), 0 the 128-row kernel (sage_attn.hip), 1 the 256-row kernel
+// (sage_attn64.hip) wherever it is eligible.  Initialised from the environment variable SAGE_ATTN64; tests and benchmarks set it.
+int attn64_mode();
+void set_attn64_mode(int mode);
+
 // ---- INT8 quantisation of Q / K ----------------------------------------------------------------
 enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style
 enum : int { GR_BLOCK = 1, GR_WARP = 2, GR_THREAD_Q = 3, GR_THREAD_K = 5 };  // row -> scale group map

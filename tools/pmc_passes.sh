@@ -17,7 +17,7 @@ for grp in "$@"; do
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "sage_attn_kernel" in r["Kernel_Name"]:
+    if "sage_attn" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:32s} {sum(v)/len(v):.5e}   (n={len(v)})")
