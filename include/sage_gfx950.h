@@ -60,6 +60,12 @@ extern "C" {
 /* PV accumulation */
 #define SAGE_PV_ACCUM_SINGLE 0       /* accumulate every tile straight into the FP32 output          */
 #define SAGE_PV_ACCUM_TWO_LEVEL 1    /* per-64-key tile product from zero, then added to FP32 output */
+#define SAGE_PV_ACCUM_TRITON 2       /* FP16 PV only: the reference's Triton kernel form (attn_qk_int8_per_block.py:53-62): the tile
+                                        product is folded into the FP32 output and the softmax denominator sums the UN-rounded
+                                        probabilities.  0 / 1 on an FP16-PV entry point select its CUDA kernel form
+                                        (qk_int_sv_f16_cuda_sm80.cu:303-320): FP32 accumulation (gfx950 MFMAs have no FP16
+                                        accumulator; both values run alike) and the denominator sums the fp16-ROUNDED
+                                        probabilities, as the reference's tensor-core row sum does. */
 
 SAGE_API int sage_abi_version(void);
 SAGE_API const char *sage_last_error(void);

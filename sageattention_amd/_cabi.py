@@ -20,7 +20,7 @@ DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
 QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
-PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL = 0, 1
+PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL, PV_ACCUM_TRITON = 0, 1, 2   # 2: FP16 PV, the reference's Triton kernel form
 MASK_BOOL, MASK_F16, MASK_BF16 = 1, 2, 3
 
 # every symbol include/sage_gfx950.h declares: name -> (restype, argtypes)

@@ -79,7 +79,8 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
     o = torch.empty(q_int8.shape, dtype=out_dtype, device=q_int8.device)
     layout = 0 if tensor_layout == "NHD" else 1            # the reference's encoding (core.py:556)
-    accum = _cabi.PV_ACCUM_TWO_LEVEL if two_level else _cabi.PV_ACCUM_SINGLE
+    # two_level: True / False, or "triton" = the Triton kernel form of the FP16-PV entry point (_cabi.PV_ACCUM_TRITON)
+    accum = _cabi.PV_ACCUM_TRITON if two_level == "triton" else (_cabi.PV_ACCUM_TWO_LEVEL if two_level else _cabi.PV_ACCUM_SINGLE)
     # Under torch.compile the registered custom ops are traced; in eager mode their implementations are
     # called directly (same code, minus ~15 us of dispatcher overhead per call).
     compiling = torch.compiler.is_compiling()
@@ -265,7 +266,7 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
         o, lse = _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, dtype, tensor_layout, return_lse)
     else:
         o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                             _cabi.GRAN_PER_BLOCK, 128, 1.0, True, return_lse)
+                             _cabi.GRAN_PER_BLOCK, 128, 1.0, "triton", return_lse)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
@@ -296,7 +297,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
         _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(q_scale), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_qs), _p(cu_ks),
         _p(order), cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),
-        o.stride(0), o.stride(1), int(is_causal), 1.0, _cabi.PV_ACCUM_TWO_LEVEL, code, _stream(o))
+        o.stride(0), o.stride(1), int(is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o))
     _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
     return o[..., :head_dim_og]
 

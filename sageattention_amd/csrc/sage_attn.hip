@@ -55,23 +55,11 @@
 #ifndef SAGE_MAGIC      // the int32 QK^T accumulators start from the bit pattern of the inline constant 1/(2 pi) = 0x3E22F983 (free as
 #define SAGE_MAGIC 1    // the MFMA's C operand): read as a float they are 1/(2 pi) + s * 2^-26 exactly, so one exact v_sub_f32 (2 cycles)
 #endif                  // replaces v_cvt_f32_i32 (4) and the 2^26 goes into the scale: bit-identical scores (see sfl below)
-#ifndef SAGE_ROT        // rotated steady-state iteration: K fragments of tile t+1 are requested before PV(t), V fragments of tile t
-#define SAGE_ROT 1      // before softmax(t), the ring barrier sits between softmax and PV (no LDS latency on the critical path)
-#endif
 #ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
 #define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
 #endif
 #ifndef SAGE_PIPE16     // the software-pipelined steady-state loop for FP16 PV as well
 #define SAGE_PIPE16 1
-#endif
-#ifndef SAGE_PIPE16_ORDER   // 1: the PV MFMAs of two 32-channel tiles alternate (a third fragment set for a longer LDS lead measured no better)
-#define SAGE_PIPE16_ORDER 1
-#endif
-#ifndef SAGE_FEWNOPS    // experiment: s_nop 1 only in front of the first MFMA of each QK^T chain (FP8 pipelined loop)
-#define SAGE_FEWNOPS 0
-#endif
-#ifndef SAGE_ASMDMA     // pipelined loop: the tile's LDS-DMA as one asm statement in the SGPR-base form (32-bit lane offsets, one
-#define SAGE_ASMDMA 1   // M0 write per image, inst_offset for the second piece) instead of four builtins with 64-bit VGPR addresses
 #endif
 #ifndef SAGE_PLAIN_PV   // pipelined FP8 loop: v_mfma_f32_32x32x64_f8f6f4 instead of its block-scaled form with unit scales
 #define SAGE_PLAIN_PV 1
@@ -79,28 +67,7 @@
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
-#ifndef SAGE_LAZY       // two-level fold only on tiles where some row maximum of the wave moved (alpha != 1); otherwise the
-#define SAGE_LAZY 0     // tile product accumulates straight into O through the MFMA's FP32 C operand
-#endif
-#ifndef SAGE_LAZY1      // experiment: single-level accumulation skips the O rescale on tiles where no row maximum moved
-#define SAGE_LAZY1 0
-#endif
-#ifndef SAGE_FORCE_SINGLE   // experiment: run two-level requests on the single-level instantiation
-#define SAGE_FORCE_SINGLE 0
-#endif
-#ifndef SAGE_QKNOP      // experiment: s_nop 7 x N after every QK^T MFMA of the steady iteration
-#define SAGE_QKNOP 0
-#endif
-#ifndef SAGE_PVNOP      // experiment: s_nop 7 x N after every PV MFMA
-#define SAGE_PVNOP 0
-#endif
 
-#ifndef SAGE_ABL        // timing ablations of the rotated steady iteration (results are garbage): bit 0 no softmax VALU, 1 no QK^T MFMAs,
-#define SAGE_ABL 0      // 2 no PV MFMAs, 3 no LDS-DMA, 4 no barrier, 5 no K ds_reads, 6 no V ds_reads, 7 no row max, 8 no exp2, 9 no fp8 pack
-#endif
-#ifdef SAGE_FORCE_WAVES // experiment: one waves/SIMD bound for every instantiation
-#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) SAGE_FORCE_WAVES
-#endif
 #ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow.  The software-pipelined FP8 loop carries two
                         // score tiles at D=128 (248 VGPRs: 2 waves; measured equal to 3 waves for the phased loop); D=64 fits 3 (167).
                         // Phased loops: 3 (<= 168 VGPRs, +3.5% measured) wherever that does not spill.
@@ -130,7 +97,7 @@ __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2
 // 0x3E22F983 lies mid-binade ([0.125, 0.25), ulp 2^-26, mantissa field 2292099): for |s| <= 128 * 128 * 128 = 2097152 the sum
 // stays inside the binade, so bits + s is the float 1/(2 pi) + s * 2^-26, the subtraction below is exact (Sterbenz) and
 // fma(s * 2^-26, c * 2^26, -m) rounds the same real number as fma((float)s, c, -m): bit-identical to the conversion.
-constexpr int kSInit = SAGE_MAGIC ? 0x3E22F983 : 0;
+[[maybe_unused]] constexpr int kSInit = SAGE_MAGIC ? 0x3E22F983 : 0;
 constexpr float kSUnit = SAGE_MAGIC ? 67108864.0f : 1.0f;       // 2^26: folded into the score scale
 __device__ __forceinline__ float sfl(int x)
 {
@@ -153,15 +120,6 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
     const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, z, 0, 0, 0);
 #endif
-}
-template <int N> __device__ __forceinline__ void nop7()
-{
-    if constexpr (N > 0) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < N; i++) asm volatile("s_nop 7");
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue
@@ -266,9 +224,6 @@ sage_attn_kernel(const AttnParams p)
         n_iters = lim < n_iters ? lim : n_iters;
     }
 
-#ifdef SAGE_HACK_NOLOOP      // timing experiment only: no tiles at all -- what one workgroup costs outside its tile loop
-    n_iters = SAGE_HACK_NOLOOP;
-#endif
     // ---- Q fragments (B operand of S^T = K Q^T), resident in VGPRs ---------------------------
     v4i qf[C::KSTEPS];
     float qsc;
@@ -432,13 +387,7 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             v4i z = {0, 0, 0, 0};
-#ifdef SAGE_HACK_NOQ         // timing experiment only: no Q loads
-            qf[ks] = v4i{lane, ks, lane * 3, 7};
-#elif defined(SAGE_HACK_QHOT) // timing experiment only: every workgroup reads the first 128 rows of the tensor (cache-hot, realistic values)
-            qf[ks] = *reinterpret_cast<const v4i *>(reinterpret_cast<const int8_t *>(p.q) + (long)(wave * 32 + n) * p.q_sl + 32 * ks + 16 * g);
-#else
             qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
-#endif
         }
         // this lane's query-row scale (per-block / per-warp / per-thread granularity)
         int slot;
@@ -448,13 +397,7 @@ sage_attn_kernel(const AttnParams p)
         else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
         else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
         else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
-#ifdef SAGE_HACK_NOQ
-        qsc = 0.01f + 1e-6f * slot;
-#elif defined(SAGE_HACK_QHOT)
-        qsc = p.q_scale[slot];
-#else
         qsc = qs_ptr[slot * qs_stride];
-#endif
     } else {
         // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
         // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
@@ -574,7 +517,6 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                     for (int sb = 0; sb < NS; sb++) {
                         s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
-                        nop7<SAGE_QKNOP>();
                     }
             } else
 #endif
@@ -642,21 +584,24 @@ sage_attn_kernel(const AttnParams p)
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             if (!TWO_LEVEL) {
-#if SAGE_LAZY1
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0)
-#endif
-                {
 #pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++)
+                for (int dt = 0; dt < C::DT; dt++)
 #pragma unroll
-                        for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
-                }
+                    for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
             }
 
             // P for chunk c (16 keys) of half hh = registers 8u..8u+7 of S^T tile 2hh + (c>>1):
             // exactly the order of the PV B operand (sage_common.h)
+            // Row sum.  The reference's FP16-PV CUDA kernels sum the fp16-ROUNDED probabilities (RS_32_to_16, then the tensor-core
+            // row sum mma::rowsum_f16f16f32: qk_int_sv_f16_cuda_sm80.cu:313-320, attn_utils.cuh:529-545, DenominatorAccumUnit =
+            // kTensorCore in every instantiation); its Triton kernels and FP8 kernels sum the un-rounded ones
+            // (attn_qk_int8_per_block.py:57-60, qk_int_sv_f8_cuda_sm90.cu:317-318).  For FP16 PV the C ABI maps the two forms onto
+            // the TWO_LEVEL parameter: false = the CUDA kernels' form (SAGE_PV_ACCUM_SINGLE / _TWO_LEVEL: gfx950 accumulates P.V
+            // in FP32 whatever tile buffer the reference would use), true = the Triton kernels' form
+            // (SAGE_PV_ACCUM_TRITON: tile product folded into the FP32 output, un-rounded denominator).
+            constexpr bool sum_rounded = !PV_FP8 && !TWO_LEVEL;
             float rs = 0.0f;
-            auto p_chunk = [&](auto masked, int hh, int c, float (&e)[8]) {
+            auto p_chunk = [&](auto masked, auto rnd, int hh, int c, float (&e)[8]) {
                 const int sb = 2 * hh + (c >> 1), r0 = (c & 1) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -675,7 +620,8 @@ sage_attn_kernel(const AttnParams p)
                         }
                     }
                     e[j] = v;
-                    rs += v;
+                    if constexpr (decltype(rnd)::value) rs += (float)(_Float16)v;
+                    else rs += v;
                 }
             };
 
@@ -687,7 +633,7 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             float e[8];
-                            p_chunk(masked, hh, c, e);
+                            p_chunk(masked, std::false_type{}, hh, c, e);
                             int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], __float_as_int(e[0]), false);   // high half is overwritten next
                             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
                             int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], __float_as_int(e[4]), false);
@@ -728,7 +674,6 @@ sage_attn_kernel(const AttnParams p)
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[2], vb[3]), SAGE_L(pw[hh][6], pw[hh][7]), acc, 0, 0, 0);
 #undef SAGE_L
 #endif
-                                nop7<SAGE_PVNOP>();
                             }
                         }
                         if (FOLD) {
@@ -738,23 +683,22 @@ sage_attn_kernel(const AttnParams p)
                     }
                 };
                 if constexpr (!TWO_LEVEL) pv(std::false_type{});
-                else if (SAGE_LAZY && __builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) pv(std::false_type{});
                 else pv(std::true_type{});
             } else {
                 v8h pb[NH][4];
-                auto build_p = [&](auto masked) {
+                auto build_p = [&](auto masked, auto rnd) {
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++)
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             float e[8];
-                            p_chunk(masked, hh, c, e);
+                            p_chunk(masked, rnd, hh, c, e);
 #pragma unroll
                             for (int j = 0; j < 8; j++) pb[hh][c][j] = (_Float16)e[j];
                         }
                 };
-                if (full) build_p(std::false_type{});
-                else build_p(std::true_type{});
+                if (full) build_p(std::false_type{}, std::integral_constant<bool, sum_rounded>{});
+                else build_p(std::true_type{}, std::integral_constant<bool, sum_rounded>{});
                 l_run = l_run * alpha + rs;
                 auto pv = [&](auto fold_tag) {
                     constexpr bool FOLD = decltype(fold_tag)::value;
@@ -784,7 +728,6 @@ sage_attn_kernel(const AttnParams p)
                     }
                 };
                 if constexpr (!TWO_LEVEL) pv(std::false_type{});
-                else if (SAGE_LAZY && __builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) pv(std::false_type{});
                 else pv(std::true_type{});
             }
         }
@@ -798,178 +741,17 @@ sage_attn_kernel(const AttnParams p)
         cur = nxt;
     };
 
-#if SAGE_ROT
-    // ---- rotated steady-state iteration (whole, unmasked tiles; FP8 PV; MASK == 0; NH == 1; 3-slot ring) ----------------
-    // Same arithmetic as tile_iter(steady) in a different order, so that no LDS or DMA latency sits between a wave's
-    // matrix phases:   QK^T(t)  [K fragments already in registers]
-    //                  request V fragments of tile t (first half now, second half once half of S is consumed)
-    //                  softmax(t)
-    //                  vmcnt(0) + s_barrier: tile t+1 has landed for every wave and every wave is past PV(t-1)
-    //                  LDS-DMA of tile t+2 into the slot of tile t-1;  request K fragments of tile t+1
-    //                  PV(t)
-    // Ring invariant at the loop top: tile t landed and barrier-synchronised, tile t+1 in flight, nothing else.
-    auto steady_rot = [&](const int it, v4i (&kf)[2][C::KSTEPS]) {
-        const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-        float ksc_next[NH][2];
-        load_kscales(it + 1, ksc_next);
-        const unsigned char *ks = smem + cur * C::STAGE_BYTES;
-        const unsigned char *vs = ks + C::K_TILE_BYTES;
-        const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
-
-        v16i s[2];
-        if constexpr ((SAGE_ABL & 2) != 0) {
-#pragma unroll
-            for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) s[sb][i] = kSInit + kf[sb][i & 3][i >> 2] + qf[i & 3][i >> 2];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < C::KSTEPS; kk++)
-#pragma unroll
-                for (int sb = 0; sb < 2; sb++)
-                    s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
-        }
-
-        // V fragments: A operand of O^T = V^T P^T, two ds_read_b128 per 32-channel tile
-        v4u va[C::DT], vb[C::DT];
-        auto read_v = [&](int dt) {
-            const int drow = dt * 32 + n;
-            const unsigned char *vr = vs + drow * 64;
-            if constexpr ((SAGE_ABL & 64) != 0) {
-                va[dt] = v4u{(unsigned)s[0][dt], (unsigned)s[0][dt + 4], (unsigned)s[0][dt + 8], (unsigned)s[1][dt]};
-                vb[dt] = v4u{(unsigned)s[1][dt + 4], (unsigned)s[1][dt + 8], (unsigned)s[0][dt + 12], (unsigned)s[1][dt + 12]};
-            } else {
-                va[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                vb[dt] = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-            }
-        };
-#pragma unroll
-        for (int dt = 0; dt < C::DT / 2; dt++) read_v(dt);
-        __builtin_amdgcn_sched_barrier(0);
-
-        float cs[2];
-        cs[0] = (p.sm_scale_log2 * (qsc * ksc[0][0])) * kSUnit;
-        cs[1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[0][1])) * kSUnit : cs[0];
-        int mx0 = INT_MIN, mx1 = INT_MIN;
-        if constexpr ((SAGE_ABL & (128 | 1)) != 0) { mx0 = s[0][0]; mx1 = s[1][2]; }
-        else {
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (KTHREAD && (i & 2)) mx1 = max(mx1, s[u][i]);
-                else mx0 = max(mx0, s[u][i]);
-            }
-        }
-        float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
-        if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
-        const float m_new = fmaxf(m_run, pair_max(mxc));
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        // The rescale sits here (not in front of the PV MFMAs) so that everything from the exponentials to the PV MFMAs is
-        // one basic block: the order pinned by the sched_barriers below survives (LLVM sinks code across a later branch).
-        if constexpr (!TWO_LEVEL || SAGE_DIRECT) {
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-                for (int dt = 0; dt < C::DT; dt++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
-            }
-        }
-
-        float rs = 0.0f;
-        int pw[8];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int sb = c >> 1, r0 = (c & 1) * 8;
-            float e[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int i = r0 + j;
-                if constexpr ((SAGE_ABL & 1) != 0) e[j] = __int_as_float(s[sb][i]);
-                else if constexpr ((SAGE_ABL & 256) != 0) { e[j] = __builtin_fmaf(sfl(s[sb][i]), cs[(KTHREAD && (i & 2)) ? 1 : 0], -m_new); rs += e[j]; }
-                else { e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sfl(s[sb][i]), cs[(KTHREAD && (i & 2)) ? 1 : 0], -m_new)); rs += e[j]; }
-            }
-            int w0, w1;
-            if constexpr ((SAGE_ABL & (512 | 1)) != 0) {
-                w0 = __float_as_int(e[0]) ^ __float_as_int(e[1]) ^ __float_as_int(e[2]) ^ __float_as_int(e[3]);
-                w1 = __float_as_int(e[4]) ^ __float_as_int(e[5]) ^ __float_as_int(e[6]) ^ __float_as_int(e[7]);
-                if constexpr ((SAGE_ABL & 1) != 0) { w0 = s[sb][r0] ^ s[sb][r0 + 3]; w1 = s[sb][r0 + 4] ^ s[sb][r0 + 7]; }
-            } else {
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], __float_as_int(e[0]), false);
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], __float_as_int(e[4]), false);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
-            }
-            pw[2 * c] = w0;
-            pw[2 * c + 1] = w1;
-            if (c == 1) {                 // S sub-tile 0 is consumed: its registers take the second half of the V fragments
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dt = C::DT / 2; dt < C::DT; dt++) read_v(dt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        l_run = l_run * alpha + rs;
-
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
-        if constexpr ((SAGE_ABL & 8) == 0) issue_loads(std::true_type{}, it + 2, nn);
-#pragma unroll
-        for (int sb = 0; sb < 2; sb++) {
-            const int krow = sb * 32 + n;
-#pragma unroll
-            for (int kk = 0; kk < C::KSTEPS; kk++) {
-                if constexpr ((SAGE_ABL & 32) != 0) kf[sb][kk] = v4i{pw[kk], pw[kk + 4], pw[2 * sb], pw[2 * sb + 1]};
-                else kf[sb][kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        const v8i bv = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
-        if constexpr (!TWO_LEVEL || SAGE_DIRECT) {
-#pragma unroll
-            for (int dt = 0; dt < C::DT; dt++) {
-                const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3], (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
-                if constexpr ((SAGE_ABL & 4) != 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[dt][i] = __int_as_float(__float_as_int(o[dt][i]) ^ av[i] ^ bv[i]);
-                } else o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, o[dt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-            }
-        } else {
-#pragma unroll
-            for (int dt = 0; dt < C::DT; dt++) {
-                const v8i av = {(int)va[dt][0], (int)va[dt][1], (int)va[dt][2], (int)va[dt][3], (int)vb[dt][0], (int)vb[dt][1], (int)vb[dt][2], (int)vb[dt][3]};
-                v16f acc;
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-#pragma unroll
-                for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
-            }
-        }
-        ksc[0][0] = ksc_next[0][0];
-        ksc[0][1] = ksc_next[0][1];
-        cur = nxt;
-    };
-#endif
     int it = 0;
 #if SAGE_STEADY
     if constexpr (MASK == 0 && NH == 1 && NSTAGE == 3) {
         // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
-#ifdef SAGE_HACK_NODIAG      // timing experiment only (wrong results): diagonal tiles run unmasked through the steady loop
-        { int ns2 = Lk / KT - 2; n_steady = ns2 < n_iters ? ns2 : n_iters; }
-#else
         if (CAUSAL) {                                  // unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk - kchunk0
             int nd = (qblk * BLKQ - kchunk0) / KT;
             nd = nd > 0 ? nd : 0;
             n_steady = n_steady < nd ? n_steady : nd;
         }
-#endif
 
 #if SAGE_PIPE
         if constexpr (PV_FP8 && SAGE_MXPV && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
@@ -995,11 +777,7 @@ sage_attn_kernel(const AttnParams p)
 #define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
 #define A_PKLO(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
 #define A_PKHI(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(a), "v"(b))
-#if SAGE_FEWNOPS
-#define SAGE_NOPX ""
-#else
 #define SAGE_NOPX "s_nop 1\n\t"
-#endif
 #if SAGE_PLAIN_PV    // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix (same products; 8 bytes and one VGPR less per MFMA)
 #define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #else
@@ -1031,12 +809,10 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
                 [[maybe_unused]] const int e8m0 = 0x7f7f7f7f;     // unit block scales (SAGE_PLAIN_PV == 0)
-#if SAGE_ASMDMA
                 static_assert(KP / 4 == VP / 4 && (KP / 4 == 1 || KP / 4 == 2), "asm LDS-DMA: one or two pieces per wave and image");
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
                 const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;    // piece 1's source offset minus its inst_offset
-#endif
                 const float sm26 = p.sm_scale_log2 * kSUnit;
                 float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
                 auto rescale = [&]() {
@@ -1054,14 +830,9 @@ sage_attn_kernel(const AttnParams p)
                     const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
                     const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
-#ifdef SAGE_HACK_NOVMWAIT     // timing experiment only (racy): how much does the wait for tile t+1 cost?
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-                    if constexpr ((SAGE_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
-                    if constexpr ((SAGE_ABL & 8) == 0) {
-#if SAGE_ASMDMA
+                    __builtin_amdgcn_s_barrier();
+                    {
                         // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
                         // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
                         const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
@@ -1083,9 +854,6 @@ sage_attn_kernel(const AttnParams p)
                                          "global_load_lds_dwordx4 %6, %3\n\t"
                                          "s_mov_b32 m0, %0"
                                          : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
-#else
-                        issue_loads(std::true_type{}, it + 2, nn);
-#endif
                     }
                     float cs[2];                 // (sm * (q_scale * k_scale)) * 2^26 == (sm * 2^26) * (q_scale * k_scale): exact power-of-two scaling
                     cs[0] = sm26 * (qsc * ksc[0][0]);
@@ -1094,20 +862,17 @@ sage_attn_kernel(const AttnParams p)
                     // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
                     // (nothing is in flight on lgkmcnt here, so hipcc's own wait for the V fragments in front of this MFMA is free;
                     //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
-                    if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[0], vf[0], pp, e8m0);
+                    A_PV(o[0], vf[0], pp, e8m0);
                     A_FENCE();
                     float ksc_next[NH][2];
                     load_kscales(it + 1, ksc_next);
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        if constexpr ((SAGE_ABL & 32) != 0) kfa[kk] = qf[kk];
-                        else kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                        kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
                     }
                     A_FENCE();
                     int mx0 = INT_MIN, mx1 = INT_MIN;
-                    if constexpr ((SAGE_ABL & 128) != 0) { mx0 = sc[0][0]; mx1 = sc[0][2]; }
-                    else {
 #pragma unroll
                     for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -1115,18 +880,16 @@ sage_attn_kernel(const AttnParams p)
                             if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
                             else mx0 = max(mx0, sc[u][i]);
                         }
-                    }
                     float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
                     if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
                     const float m_new = fmaxf(m_run, pair_max(mxc));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
-                    if constexpr (C::DT > 1 && (SAGE_ABL & 4) == 0) A_PV(o[1], vf[1], pp, e8m0);
+                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
                     A_FENCE();
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        if constexpr ((SAGE_ABL & 32) != 0) kfb[kk] = qf[kk];
-                        else kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                        kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
                     }
                     A_FENCE();
 
@@ -1135,7 +898,6 @@ sage_attn_kernel(const AttnParams p)
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
-                        if constexpr ((SAGE_ABL & 1) != 0) return;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
 #define SAGE_GRP(PACK)                                                                                                          \
@@ -1150,12 +912,10 @@ sage_attn_kernel(const AttnParams p)
 #undef SAGE_GRP
                     };
                     auto qk_next = [&](int sb, int kk) {
-                        if constexpr ((SAGE_ABL & 2) != 0) return;
                         if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
                         else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
                     };
                     auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
-                        if constexpr ((SAGE_ABL & 64) != 0) return;
                         const int drow = dt * 32 + n;
                         const unsigned char *vr = vs + drow * 64;
                         const v4u a = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
@@ -1163,9 +923,9 @@ sage_attn_kernel(const AttnParams p)
                         vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
                     };
                     if constexpr (C::DT == 4) {
-                        if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[2], vf[2], pp, e8m0);
+                        A_PV(o[2], vf[2], pp, e8m0);
                         grp(0); grp(1);
-                        if constexpr ((SAGE_ABL & 4) == 0) A_PV(o[3], vf[3], pp, e8m0);
+                        A_PV(o[3], vf[3], pp, e8m0);
                         grp(2); grp(3);
                         qk_next(0, 0); grp(4);
                         qk_next(0, 1); grp(5); grp(6);
@@ -1277,6 +1037,9 @@ sage_attn_kernel(const AttnParams p)
                     }
                 };
                 bool first = true;                 // no previous tile yet: P = 0 against the (finite) V of the current slot
+                // CUDA kernel form (TWO_LEVEL false): row sum of the fp16-rounded P; Triton kernel form (TWO_LEVEL true): of the
+                // un-rounded P (see tile_iter)
+                constexpr bool RSUM16 = !TWO_LEVEL;
                 auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
                     rescale();
                     const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
@@ -1341,18 +1104,34 @@ sage_attn_kernel(const AttnParams p)
                     A_FENCE();
 
                     float rs0 = 0.0f, rs1 = 0.0f;
-                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32: bias sub, scale fma, exp2, row-sum add, fp16 pack
+                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32: bias sub, scale fma, exp2, fp16 pack, row sum
                         const int c = h >> 2, j0 = (h & 3) * 2;
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
-                        asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
-                                     "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
-                                     "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
-                                     "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
-                                     "v_cvt_pk_f16_f32 %4, %2, %3"
-                                     : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=v"(pc[c][h & 3])
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                        if constexpr (RSUM16) {
+                            // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
+                            // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
+                            // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
+                            // outputs 0.6-1.7 % too large on Lk = 333 with per-block scales).  The reference takes this sum from the
+                            // tensor core (see tile_iter).
+                            asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
+                                         "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
+                                         "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+                                         "s_nop 0\n\tv_cvt_pk_f16_f32 %4, %2, %3\n\t"
+                                         "v_fma_mix_f32 %0, %4, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                                         "v_fma_mix_f32 %1, %4, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                         : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                        } else {
+                            asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
+                                         "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
+                                         "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+                                         "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
+                                         "v_cvt_pk_f16_f32 %4, %2, %3"
+                                         : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=v"(pc[c][h & 3])
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                        }
                     };
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
                     auto read_k = [&](int sb, v4i (&kf)[C::KSTEPS]) {
@@ -1370,28 +1149,6 @@ sage_attn_kernel(const AttnParams p)
                         // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
                         // Two 32-channel tiles are in flight and their MFMAs alternate, so consecutive MFMAs never share an
                         // accumulator (a dependent MFMA issued behind other instructions waits for the full write-back).
-#if SAGE_PIPE16_ORDER == 0
-                        pv4(0, vfa, 0); grp(0);
-                        pv4(0, vfa, 1); grp(1);
-                        pv4(0, vfa, 2); pv4(0, vfa, 3); grp(2);
-                        A_FENCE(); read_v(2, vfa); A_FENCE();
-                        pv4(1, vfb, 0); grp(3);
-                        pv4(1, vfb, 1); grp(4);
-                        pv4(1, vfb, 2); pv4(1, vfb, 3); grp(5);
-                        A_FENCE(); read_v(3, vfb); A_FENCE();
-                        pv4(2, vfa, 0); grp(6);
-                        pv4(2, vfa, 1); grp(7);
-                        pv4(2, vfa, 2); pv4(2, vfa, 3); grp(8);
-                        A_FENCE(); read_k(0, kfa); A_FENCE();
-                        pv4(3, vfb, 0); grp(9);
-                        pv4(3, vfb, 1); grp(10);
-                        pv4(3, vfb, 2); pv4(3, vfb, 3); grp(11);
-                        A_FENCE(); read_k(1, kfb); A_FENCE();
-                        qk_next(0, 0); qk_next(0, 1); grp(12);
-                        qk_next(0, 2); qk_next(0, 3); grp(13);
-                        qk_next(1, 0); qk_next(1, 1); grp(14);
-                        qk_next(1, 2); qk_next(1, 3); grp(15);
-#else
                         pv4(0, vfa, 0); grp(0);
                         pv4(1, vfb, 0); grp(1);
                         pv4(0, vfa, 1); pv4(1, vfb, 1); grp(2);
@@ -1416,7 +1173,6 @@ sage_attn_kernel(const AttnParams p)
                         qk_next(0, 1); qk_next(1, 1); grp(14);
                         qk_next(0, 2); qk_next(1, 2); grp(15);
                         qk_next(0, 3); qk_next(1, 3);
-#endif
                     } else {                         // D = 64: 8 PV + 4 QK^T MFMAs
                         pv4(0, vfa, 0); grp(0);
                         pv4(0, vfa, 1); grp(1);
@@ -1499,25 +1255,6 @@ sage_attn_kernel(const AttnParams p)
 #undef A_FENCE
         } else
 #endif
-#if SAGE_ROT
-        if constexpr (PV_FP8 && SAGE_MXPV) {
-            if (it < n_steady) {
-                v4i kf[2][C::KSTEPS];
-                const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
-#pragma unroll
-                for (int sb = 0; sb < 2; sb++) {
-                    const int krow = sb * 32 + n;
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-                        kf[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                }
-#pragma nounroll
-                for (; it < n_steady; it++) steady_rot(it, kf);
-                // back to the general discipline (DMA of tile it+2 at the top of iteration it): every wave must be past PV(it-1)
-                __builtin_amdgcn_s_barrier();
-            }
-        } else
-#endif
         {
 #pragma nounroll
             for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
@@ -1527,10 +1264,6 @@ sage_attn_kernel(const AttnParams p)
 #pragma nounroll
     for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
-#ifdef SAGE_HACK_NOEPI       // timing experiment only: one store per wave instead of the epilogue
-    if (lane == 0) reinterpret_cast<float *>(p.o)[(o_off + (long)row0 * p.o_sl) / 2] = o[0][0] + o[1][1] + l_run + m_run;
-    return;
-#endif
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
     const float l_tot = pair_sum(l_run);
@@ -1632,20 +1365,13 @@ template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
 static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
 {
     using C = TileCfg<D, PV_FP8, NH>;
-#ifdef SAGE_LDS_MIN_BYTES   // experiments: cap workgroups per CU through the LDS budget
-    constexpr int lds = C::LDS_BYTES > SAGE_LDS_MIN_BYTES ? C::LDS_BYTES : SAGE_LDS_MIN_BYTES;
-#else
     constexpr int lds = C::LDS_BYTES;
-#endif
     return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>, lds, p, nwork, stream);
 }
 
 template <int D, bool PV_FP8, int NH>
 static hipError_t launch_d(const AttnParams &p, int nwork, bool causal, bool kthread, bool two_level, hipStream_t s)
 {
-#if SAGE_FORCE_SINGLE
-    two_level = false;
-#endif
 #define SAGE_CASE(C_, K_, T_) if (causal == C_ && kthread == K_ && two_level == T_) return launch_one<D, PV_FP8, C_, K_, T_, NH>(p, nwork, s);
     SAGE_CASE(false, false, false) SAGE_CASE(false, false, true)
     SAGE_CASE(true, false, false)  SAGE_CASE(true, false, true)

@@ -94,7 +94,11 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
         p.mask = mask->ptr; p.m_sb = mask->sb; p.m_sh = mask->sh; p.m_sq = mask->sq; p.m_sk = mask->sk;
         mask_kind = mask->kind;
     }
-    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, pv_accum == SAGE_PV_ACCUM_TWO_LEVEL, mask_kind,
+    SAGE_REQUIRE(pv_accum >= SAGE_PV_ACCUM_SINGLE && pv_accum <= SAGE_PV_ACCUM_TRITON && (!fp8 || pv_accum != SAGE_PV_ACCUM_TRITON),
+                 "bad pv_accum %d", pv_accum);
+    // FP16 PV: the kernel's TWO_LEVEL parameter selects the Triton kernel form (true) or the CUDA kernel form (false)
+    const bool two_level = fp8 ? pv_accum == SAGE_PV_ACCUM_TWO_LEVEL : pv_accum == SAGE_PV_ACCUM_TRITON;
+    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, two_level, mask_kind,
                                           static_cast<hipStream_t>(stream)), "sage_attn launch");
 }
 
@@ -360,7 +364,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
     const MaskArg m{mask, mask_kind, m_sb, m_sh, m_sq, m_sk};
     return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-                       0, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, SAGE_PV_ACCUM_TWO_LEVEL, out_dtype, stream, &m);
+                       0, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, SAGE_PV_ACCUM_TRITON, out_dtype, stream, &m);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
