@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 10
+#define SAGE_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -154,17 +154,26 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  * Either of k / v may be NULL to run one half.  Results are bit-identical to the sage_channel_mean +
  * sage_quant_qk_int8 + sage_prep_v_fp8 sequence (6 launches, 4 B/elt read): same per-slab summation order.
  *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
- *   sync  sage_prepass_sync_words(B,H) uint32, ZERO before the first call; the kernel leaves it zero again, so calls issued
- *         in stream order may share it -- concurrent calls (other streams) need their own.  Layout: 32 words per (K|V, b, h):
- *         [0] arrivals, [1] departures, [2] sticky flag set if a workgroup waited ~1 s for its head in vain (results
- *         of that call are then wrong; never observed -- a debugging aid, the kernel does not clear it)
+ *   sync  sage_prepass_sync_words(B,H) uint32 of scratch, private to the call while it runs (it need not be initialised: the
+ *         entry point zeroes it on `stream` before the launch).  Layout: 32 words per (K|V, b, h):
+ *         [0] arrivals, [1] departures, [2] give-up flag: set if a workgroup waited ~1 s for the other slabs of its head in
+ *         vain (the co-residency assumption below was violated).  Giving up is loud: such a workgroup, and every workgroup
+ *         of the head that leaves the wait after it, writes NaN scales (K) / NaN image bytes and a NaN v_scale (V), so the
+ *         attention call that consumes the pre-pass returns NaN for the affected head instead of a plausible wrong number.
+ *         sage_prepass_failed_heads(sync, B, H, stream) synchronises the stream and returns how many (K|V, b, h) entries
+ *         carry the flag (0 = the launch was sound).
  *   L     at most sage_prepass_max_seqlen() (32768 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
  *         head wait for each other inside the launch, so all of them must fit on the device at once; longer
- *         sequences take the three-call sequence (SAGE_EINVAL here)
+ *         sequences take the three-call sequence (SAGE_EINVAL here).  The bound uses the compute units `stream` may use
+ *         (hipExtStreamGetCUMask).  Per head, ((ceil(L/512)*512 - 1) * row stride + D) * 2 must stay below 2^32.
  */
 SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D);
 SAGE_API int64_t sage_prepass_sync_words(int B, int H);
 SAGE_API int sage_prepass_max_seqlen(void);
+SAGE_API int sage_prepass_failed_heads(const uint32_t *sync, int B, int H, void *stream);
+/* test hook: non-zero makes every following sage_prepass_kv launch wait for a slab that does not exist and give up after
+ * 2^10 polls, i.e. exercises the give-up path above (process-wide; reset with 0) */
+SAGE_API void sage_debug_prepass_fail(int on);
 SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
                     void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
                     int B, int H, int L, int D,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 10
+ABI_VERSION = 11
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -41,6 +41,8 @@ SYMBOLS = {
     "sage_prepass_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_prepass_sync_words": (c_int64, [_I, _I]),
     "sage_prepass_max_seqlen": (c_int, []),
+    "sage_prepass_failed_heads": (c_int, [_P, _I, _I, _P]),
+    "sage_debug_prepass_fail": (None, [_I]),
     "sage_prepass_kv": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                 _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
     "sage_prep_v_f16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),

@@ -12,6 +12,8 @@ tensors or a missing library raise.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 import warnings
 from typing import Any, Optional
@@ -346,6 +348,11 @@ def _fused_prepass_wanted(k, tensor_layout: str, override: Optional[bool]) -> bo
         return False
     if override is not None:
         return bool(override)
+    env = os.environ.get("SAGE_PREPASS", "")      # "seq" / "fused": force a route for every call (debugging, CU-masked streams)
+    if env in ("seq", "sequence", "0"):
+        return False
+    if env in ("fused", "1"):
+        return True
     B, H, L = _dims(k, tensor_layout)[:3]
     return L > 256 or B * H <= 256
 

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -250,6 +251,24 @@ SAGE_API int64_t sage_prepass_sync_words(int B, int H) { return 2 * (int64_t)B *
 // Longest head the in-launch barrier takes on the current device: at most kPrepassMaxSlabs slabs, and never more than one per
 // compute unit of the device (or partition) the caller runs on -- every slab of a head must be able to be resident while its
 // head-mates arrive, with room left for the workgroups of the heads before it (2 resident workgroups per CU at D = 128).
+static int g_prepass_debug_fail = 0;
+SAGE_API void sage_debug_prepass_fail(int on) { g_prepass_debug_fail = on ? 1 : 0; }
+
+// compute units a launch on `stream` can use: the stream's CU mask if it has one (hipExtStreamCreateWithCUMask), else the device's
+static int stream_cu_count(hipStream_t stream, int dev)
+{
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    uint32_t mask[16] = {0};
+    if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess) {
+        int bits = 0;
+        for (int i = 0; i < 16; i++) bits += __builtin_popcount(mask[i]);
+        if (bits > 0 && bits < cus) cus = bits;
+    }
+    (void)hipGetLastError();
+    return cus;
+}
+
 SAGE_API int sage_prepass_max_seqlen(void)
 {
     static thread_local int cached_dev = -1, cached_len = 0;
@@ -265,6 +284,22 @@ SAGE_API int sage_prepass_max_seqlen(void)
     return cached_len;
 }
 
+SAGE_API int sage_prepass_failed_heads(const uint32_t *sync, int B, int H, void *stream)
+{
+    if (!sync || B <= 0 || H <= 0) return fail(SAGE_EINVAL, "bad arguments");
+    const size_t words = (size_t)2 * B * H * sage::kPrepassSyncStride;
+    uint32_t *host = static_cast<uint32_t *>(malloc(words * sizeof(uint32_t)));
+    if (!host) return fail(SAGE_ELAUNCH, "out of host memory");
+    hipError_t e = hipMemcpyAsync(host, sync, words * sizeof(uint32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    int n = 0;
+    if (e == hipSuccess)
+        for (size_t i = 0; i < (size_t)2 * B * H; i++) n += host[i * sage::kPrepassSyncStride + 2] != 0;
+    free(host);
+    if (e != hipSuccess) return fail(SAGE_ELAUNCH, "sage_prepass_failed_heads: %s", hipGetErrorString(e));
+    return n;
+}
+
 SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
                     void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
                     int B, int H, int L, int D,
@@ -273,13 +308,23 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
                     int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, void *stream)
 {
     SAGE_REQUIRE(k || v, "nothing to do: both k and v are null");
-    SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its (zeroed) sync buffer");
+    SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its sync buffer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
     SAGE_REQUIRE(B > 0 && H > 0 && L > 0, "empty tensor");
     SAGE_REQUIRE(B <= 32767 && H <= 65535, "batch / head count too large for one launch (%d, %d)", B, H);
     SAGE_REQUIRE(L <= sage_prepass_max_seqlen(), "sequence too long for the in-launch head barrier (%d > %d): use the "
                  "sage_channel_mean / sage_quant_qk_int8 / sage_prep_v_fp8 sequence", L, sage_prepass_max_seqlen());
+    {   // the slabs of a head must be co-resident: a stream restricted to a CU mask has fewer compute units than the device
+        int dev = 0;
+        SAGE_REQUIRE(hipGetDevice(&dev) == hipSuccess, "no current device");
+        const int cus = stream_cu_count(static_cast<hipStream_t>(stream), dev);
+        const int nslab_ = (L + sage::kStatsSlab - 1) / sage::kStatsSlab;
+        SAGE_REQUIRE(nslab_ <= cus, "a head of %d slabs cannot be co-resident on the %d compute units this stream may use: use the "
+                     "sage_channel_mean / sage_quant_qk_int8 / sage_prep_v_fp8 sequence", nslab_, cus);
+    }
     SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    // rows of the last slab past L are read through the buffer range check: their 32-bit byte offsets must not wrap either
+    const int64_t lpad = ((int64_t)L + sage::kStatsSlab - 1) / sage::kStatsSlab * sage::kStatsSlab;
     sage::PrepassParams p{};
     p.parts = (k ? 1 : 0) | (v ? 2 : 0);
     if (k) {
@@ -287,8 +332,8 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(aligned16(k) && aligned16(k_int8), "k / k_int8 must be 16-byte aligned");
         SAGE_REQUIRE(k_sl % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0, "input strides must be multiples of 8 elements");
         SAGE_REQUIRE(ko_sl % 16 == 0 && ko_sh % 16 == 0 && ko_sb % 16 == 0, "int8 output strides must be multiples of 16");
-        SAGE_REQUIRE(((int64_t)(L - 1) * k_sl + D) * 2 < (int64_t)1 << 32 && (int64_t)(L - 1) * ko_sl + D < (int64_t)1 << 32,
-                     "one head of k spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
+        SAGE_REQUIRE(((lpad - 1) * k_sl + D) * 2 < (int64_t)1 << 32 && (lpad - 1) * ko_sl + D < (int64_t)1 << 32,
+                     "one head of k (rounded up to whole 512-row slabs) spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
         SAGE_REQUIRE(k_blk == 64 || k_blk == 128, "k_blk must be 64 or 128 (got %d)", k_blk);
         SAGE_REQUIRE(k_style == sage::QS_CUDA || k_style == sage::QS_TRITON_THREAD, "k_style must be the CUDA (1) or the per-thread Triton (2) convention (got %d)", k_style);
         if (qk_quant_gran == SAGE_GRAN_PER_BLOCK) p.k_gran = sage::GR_BLOCK;
@@ -299,8 +344,8 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(v_image && (v_scale || v_fp16), "V part needs v_image (and v_scale for the FP8 image)");
         SAGE_REQUIRE(aligned16(v) && aligned16(v_image), "v / v_image must be 16-byte aligned");
         SAGE_REQUIRE(v_sl % 8 == 0 && v_sh % 8 == 0 && v_sb % 8 == 0, "input strides must be multiples of 8 elements");
-        SAGE_REQUIRE(((int64_t)(L - 1) * v_sl + D) * 2 < (int64_t)1 << 32,
-                     "one head of v spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
+        SAGE_REQUIRE(((lpad - 1) * v_sl + D) * 2 < (int64_t)1 << 32,
+                     "one head of v (rounded up to whole 512-row slabs) spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
         SAGE_REQUIRE(v_fp16 || scale_max > 0.0f, "scale_max must be positive");
         SAGE_REQUIRE(!(v_fp16 && v_mean), "the fp16 image has no smooth_v (use sage_prep_v_f16 with a mean for sub_mean)");
     }
@@ -310,6 +355,9 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
     p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
     p.ko_sb = ko_sb; p.ko_sh = ko_sh; p.ko_sl = ko_sl;
     p.k_blk = k_blk; p.k_warp = k_blk; p.k_style = k_style; p.dtype = dtype; p.scale_max = scale_max; p.v_fp16 = v_fp16 ? 1 : 0;
+    p.debug_fail = g_prepass_debug_fail;
+    // the per-head counters and give-up flags start from zero in every launch (a launch that gave up leaves them dirty); launch_prepass_kv
+    // zeroes them with a small kernel of its own (a hipMemsetAsync node replayed wrongly inside a captured HIP graph on ROCm 7.0)
     return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv launch");
 }
 

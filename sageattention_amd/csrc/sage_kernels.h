@@ -125,7 +125,8 @@ struct PrepassParams {
     float *v_scale;           // [B,H,D] out
     float *v_mean;            // nullable [B,H,D] out; non-null = smooth_v
     float *ws;                // [2,B,H,nslab,3,D] slab partials
-    unsigned *sync;           // [2,B,H,kPrepassSyncStride] arrival / departure counters, zero on entry, zero again on exit
+    unsigned *sync;           // [2,B,H,kPrepassSyncStride] per head: arrival counter, departure counter, give-up flag; zeroed by the
+                              // launcher (a small kernel on the launch stream) before every launch
     int B, H, L, D, nslab;
     long k_sb, k_sh, k_sl;
     long v_sb, v_sh, v_sl;
@@ -138,6 +139,7 @@ struct PrepassParams {
     int k_style;              // QS_*
     int dtype;
     float scale_max;          // 448 for e4m3
+    int debug_fail;           // test hook (sage_debug_prepass_fail): wait for one slab more than exists and give up after 2^10 polls
 };
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t stream);
 

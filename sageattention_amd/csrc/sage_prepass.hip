@@ -19,8 +19,12 @@
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.
 // The two counters of a head return to zero before the kernel ends, so one zero-initialised sync buffer serves every
-// call issued in stream order.  The wait is bounded: after ~1 s a workgroup gives up, sets word 2 of the head's sync line
-// (sticky, never cleared by the kernel) and carries on with whatever partials it finds.
+// call issued in stream order (the C ABI zeroes the buffer before every launch all the same: a launch that gave up must
+// not poison the next one).  The wait is bounded: after ~1 s a workgroup gives up and sets word 2 of the head's sync line.
+// Giving up is LOUD: every workgroup that leaves the wait with that word set -- the one that gave up, and any that arrive
+// later -- poisons what it writes (K: NaN scales for its blocks; V: NaN bytes in its image tiles, NaN v_scale), so the
+// attention kernel that consumes the pre-pass returns NaN for every query that attends to the affected keys instead of a
+// plausible wrong number; sage_prepass_failed_heads() reads the flags back for a host-side check.
 #include "sage_common.h"
 #include "sage_kernels.h"
 #include "sage_quant_math.h"
@@ -86,6 +90,7 @@ struct PrepassLds {
     __attribute__((aligned(16))) uint16_t tile[2][BLKK * LDT];
     float ch_mean[D], ch_recp[D];
     uint16_t kmean[D];
+    unsigned failed;          // the head's give-up flag as thread 0 found it after the wait
     unsigned gmax[8][8];
     float gsc[8][8], gy[8][8];
 };
@@ -113,6 +118,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     constexpr int LDT = D + 8;
     auto &red = lds.red; auto &tile = lds.tile; auto &ch_mean = lds.ch_mean; auto &ch_recp = lds.ch_recp;
     auto &kmean = lds.kmean; auto &gmax = lds.gmax; auto &gsc = lds.gsc; auto &gy = lds.gy;
+    bool failed = false;                        // this workgroup's statistics cannot be trusted: poison what it writes
     constexpr int is_v = IS_V ? 1 : 0;
 
     const int tid = threadIdx.x;
@@ -217,14 +223,19 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             if (tid == 0) {
                 __hip_atomic_fetch_add(cnt, 1u, SAGE_PP_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // bounded (about a second): if the forward-progress assumption above were ever violated the launch would
-                // finish with wrong numbers and a sticky flag in the head's sync line instead of hanging the device
+                // finish with NaN-poisoned outputs and a flag in the head's sync line instead of hanging the device
+                const unsigned want = (unsigned)p.nslab + (p.debug_fail ? 1u : 0u);
+                const unsigned bound = p.debug_fail ? (1u << 10) : (1u << 20);
                 unsigned polls = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nslab) {
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++polls > (1u << 20)) { __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (++polls > bound) { __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 }
+                // a workgroup that arrives after another one gave up finds the count complete -- and the flag set
+                lds.failed = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
+            failed = lds.failed != 0;
         }
         SAGE_STAMP();                              // 3: every slab of the head has arrived
         if (tid < D) {
@@ -265,7 +276,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 ch_mean[tid] = mean;
                 ch_recp[tid] = am > 0.0f ? p.scale_max / am : 0.0f;
                 if (slab == 0) {
-                    p.v_scale[bh * D + tid] = am / p.scale_max;
+                    p.v_scale[bh * D + tid] = failed ? __uint_as_float(0x7fc00000u) : am / p.scale_max;
                     if (smooth) p.v_mean[bh * D + tid] = mean;
                 }
             }
@@ -400,7 +411,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 const float sc = quant_scale(am, p.k_style);
                 gsc[kb][g] = sc;
                 gy[kb][g] = (STYLE == 0) ? 127.0f / am : quant_recip(sc);       // fused.cu:164
-                if (gb < nblk_total) p.k_scale[(bh * nblk_total + gb) * ngroups + g] = sc;
+                if (gb < nblk_total) p.k_scale[(bh * nblk_total + gb) * ngroups + g] = failed ? __uint_as_float(0x7fc00000u) : sc;
             }
             __syncthreads();
             unsigned orun = ooff;
@@ -472,7 +483,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                         for (int w = 0; w < 4; w++) {
                             int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
                             word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
-                            pk[w] = (unsigned)word;
+                            pk[w] = failed ? 0x7f7f7f7fu : (unsigned)word;       // 0x7f: e4m3fn NaN
                         }
                         if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16));
                         else *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;
@@ -540,9 +551,19 @@ prepass_kv_kernel(const PrepassParams p)
     else prepass_body<D, DT, false>(p, lds, b);
 }
 
+__global__ void __launch_bounds__(256) prepass_zero_sync_kernel(unsigned *sync, int words)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < words) sync[i] = 0u;
+}
+
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t s)
 {
     if (p.B <= 0 || p.H <= 0 || p.nslab <= 0 || p.parts == 0) return hipSuccess;
+    {
+        const int words = 2 * p.B * p.H * kPrepassSyncStride;
+        hipLaunchKernelGGL(prepass_zero_sync_kernel, dim3((words + 255) / 256), dim3(256), 0, s, p.sync, words);
+    }
     dim3 grid(p.nslab, p.H, p.B * (p.parts == 3 ? 2 : 1));
 #define SAGE_PP(D_, T_) hipLaunchKernelGGL((prepass_kv_kernel<D_, T_>), grid, dim3(kPrepassThreads), 0, s, p)
     if (p.D == 128) { if (p.dtype == DT_F16) SAGE_PP(128, DT_F16); else SAGE_PP(128, DT_BF16); }

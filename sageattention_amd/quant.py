@@ -199,6 +199,9 @@ def channel_mean_packed(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_DEBUG = bool(int(__import__("os").environ.get("SAGE_DEBUG", "0") or 0))   # SAGE_DEBUG=1: check the pre-pass give-up flags after every call (synchronises)
+
+
 @_eager
 def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = False
                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
@@ -219,43 +222,42 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     return v_image, v_scale, vm
 
 
-_sync_cache: dict = {}
-
-
 def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
-    """Zeroed arrival counters of the fused pre-pass.  The kernel leaves them zero again, so one buffer per
-    (device, stream) serves every call issued in stream order; while a HIP graph is being captured the buffer is
-    private to the capture (its zero fill becomes a node of the graph)."""
-    words = int(_cabi.load().sage_prepass_sync_words(B, H))
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros((words,), dtype=torch.int32, device=device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
-    buf = _sync_cache.get(key)
-    if buf is None or buf.numel() < words:
-        buf = torch.zeros((max(words, 4096),), dtype=torch.int32, device=device)
-        _sync_cache[key] = buf
-    return buf
+    """Scratch for the per-head counters of the fused pre-pass: a fresh, uninitialised buffer per call (the C ABI zeroes it on
+    the launch stream), so no state survives from one call to the next."""
+    return torch.empty((int(_cabi.load().sage_prepass_sync_words(B, H)),), dtype=torch.int32, device=device)
+
+
+def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
+    """Synchronise and count the (K|V, batch, head) entries of a pre-pass call whose workgroups gave up waiting for each other
+    (their outputs are NaN-poisoned; 0 = sound).  Debugging / test aid: ``SAGE_DEBUG=1`` makes ``prepass_kv_fp8`` call it."""
+    n = int(_cabi.load().sage_prepass_failed_heads(_p(sync), B, H, _stream(sync)))
+    if n < 0:
+        _cabi.check(n, "sage_prepass_failed_heads")
+    return n
 
 
 def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
     """Whether the one-launch pre-pass covers this K / V length (the slabs of a head wait for each other in the launch)."""
     _, _, L, D, _, _, sl = _dims(k, tensor_layout)
     # the kernel addresses one head with 32-bit buffer offsets (row stride x rows x 2 bytes)
-    return L <= int(_cabi.load().sage_prepass_max_seqlen()) and ((L - 1) * sl + D) * 2 < 2 ** 32
+    # (rows of the last 512-row slab past L go through the buffer range check: their offsets must not wrap either)
+    lpad = (L + 511) // 512 * 512
+    return L <= int(_cabi.load().sage_prepass_max_seqlen()) and ((lpad - 1) * sl + D) * 2 < 2 ** 32
 
 
 @_eager
 def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: str = "HND", smooth_k: bool = True,
                    smooth_v: bool = False, BLKK: int = 64, qk_quant_gran: str = "per_thread", scale_max: float = 448.0,
-                   v_fp16: bool = False):
+                   v_fp16: bool = False, sync: Optional[torch.Tensor] = None):
     """K and V pre-pass of the FP8-PV entry points in ONE launch that reads K and V once: the bits of
     ``channel_mean`` + ``per_thread_int8`` / ``per_warp_int8`` (K side) + ``per_channel_fp8``.
     Returns ``(km [B,H,D] | None, k_int8, k_scale, v_image, v_scale, vm)``; ``v=None`` runs the K half only
     (``v_image, v_scale, vm`` are None).  ``qk_quant_gran`` "per_thread" gives 4 k scales per BLKK keys with the
     Triton-per-thread rounding, "per_warp" / "per_block" one scale per BLKK keys with the CUDA rounding
     (quant.py:105-180) -- the K conventions of the reference's CUDA entry points.  ``v_fp16=True`` (FP16-PV entry points) makes
-    the V half the fp16 tile image of ``prep_v_fp16`` instead (``v_scale`` and ``vm`` are then None)."""
+    the V half the fp16 tile image of ``prep_v_fp16`` instead (``v_scale`` and ``vm`` are then None).  ``sync``: optional
+    caller-owned int32 scratch of ``sage_prepass_sync_words(B, H)`` words (to inspect with ``prepass_failed_heads`` afterwards)."""
     k = _aligned(k, 8)
     B, H, L, D, k_sb, k_sh, k_sl = _dims(k, tensor_layout)
     dev = k.device
@@ -284,11 +286,18 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
             vm = torch.empty((B, H, D), dtype=torch.float32, device=dev) if smooth_v else None
     lib = _cabi.load()
     ws = torch.empty((int(lib.sage_prepass_ws_floats(B, H, L, D)),), dtype=torch.float32, device=dev)
-    sync = _prepass_sync(B, H, dev)
+    if sync is None:
+        sync = _prepass_sync(B, H, dev)
+    assert sync.dtype == torch.int32 and sync.numel() >= int(lib.sage_prepass_sync_words(B, H)) and sync.device == dev
     rc = lib.sage_prepass_kv(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(v_scale), _p(vm), _p(ws), _p(sync),
                              B, H, L, D, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, ob, oh, ol,
                              BLKK, gran, style, float(scale_max), int(bool(v_fp16)), _dtype_code(k), _stream(k))
     _cabi.check(rc, "sage_prepass_kv")
+    if _DEBUG:
+        n = prepass_failed_heads(sync, B, H)
+        if n:
+            raise _cabi.SageKernelError(f"sage_prepass_kv: {n} (K|V, batch, head) entries gave up waiting for the other slabs of "
+                                        "their head (outputs are NaN-poisoned); is the stream restricted to few compute units?")
     return km, k_int8, k_scale, v_image, v_scale, vm
 
 

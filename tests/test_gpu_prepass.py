@@ -60,12 +60,13 @@ CASES = [  # B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran
 def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran):
     k, v = _mk(B, H, L, D, dtype, layout, 7 * L + D)
     ref = _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran)
-    for rep in range(3):                   # the sync counters must come back to zero after every call
-        got = quant.prepass_kv_fp8(k, v, layout, smooth_k=smooth_k, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran)
+    sync = torch.full((int(_cabi.load().sage_prepass_sync_words(B, H)),), 0x5a5a5a5a, dtype=torch.int32, device="cuda")   # dirty on purpose
+    for rep in range(3):                   # the same (dirty) sync buffer serves every call: the entry point zeroes it
+        got = quant.prepass_kv_fp8(k, v, layout, smooth_k=smooth_k, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran, sync=sync)
         for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, f"{name} (call {rep})")
-    key = (torch.cuda.current_device(), torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
-    assert int(quant._sync_cache[key].abs().sum().item()) == 0           # counters re-armed, no give-up flag
+    assert quant.prepass_failed_heads(sync, B, H) == 0
+    assert int(sync.abs().sum().item()) == 0           # counters re-armed by the kernel, no give-up flag
 
 
 def test_k_half_only_and_side_stream():
@@ -161,9 +162,6 @@ def test_default_prepass_choice():
     assert not core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", False)
 
 
-def _sync_flags():
-    return sum(int(b.abs().sum().item()) for b in quant._sync_cache.values())
-
 
 def test_head_barrier_makes_progress_while_other_kernels_hold_the_chip():
     """The in-launch barrier needs every slab of the lowest unfinished head to get a slot.  Crowd the device: a long attention
@@ -177,20 +175,64 @@ def test_head_barrier_makes_progress_while_other_kernels_hold_the_chip():
     ref2 = _sequence(k2, v2, "HND", True, True, 64, "per_thread")
     torch.cuda.synchronize()
     s_attn, s_pp = torch.cuda.Stream(), torch.cuda.Stream()
+    words = int(_cabi.load().sage_prepass_sync_words(2, 32))
+    syncs = [(torch.empty(words, dtype=torch.int32, device="cuda"), torch.empty(words, dtype=torch.int32, device="cuda")) for _ in range(4)]
     outs = []
     for rep in range(4):
         with torch.cuda.stream(s_attn):
             sa.sageattn(qa, qa, qa, is_causal=False)                      # ~5 ms of attention workgroups on every CU
         with torch.cuda.stream(s_pp):
-            got2 = quant.prepass_kv_fp8(k2, v2, "HND", smooth_k=True, smooth_v=True)      # 64-slab heads
-        outs.append((quant.prepass_kv_fp8(k, v, "HND", smooth_k=True), got2))
+            got2 = quant.prepass_kv_fp8(k2, v2, "HND", smooth_k=True, smooth_v=True, sync=syncs[rep][1])      # 64-slab heads
+        outs.append((quant.prepass_kv_fp8(k, v, "HND", smooth_k=True, sync=syncs[rep][0]), got2))
     torch.cuda.synchronize()
     for got, got2 in outs:
         for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, name)
         for a, b, name in zip(got2, ref2, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, name + " (64-slab heads, side stream)")
-    assert _sync_flags() == 0
+    for s0, s1 in syncs:
+        assert quant.prepass_failed_heads(s0, 2, 32) == 0 and quant.prepass_failed_heads(s1, 1, 16) == 0
+
+
+def test_a_pre_pass_that_gives_up_is_loud():
+    """The in-launch head barrier gives up after a bounded wait if the slabs of a head cannot become co-resident.  Forced here with
+    the debug hook (every workgroup waits for a slab that does not exist): the give-up flags are set, the pre-pass outputs are
+    NaN-poisoned, sageattn() returns NaN for every head with more than one slab -- never a plausible wrong number -- and the
+    next call (hook off, fresh scratch) is sound again."""
+    import sageattention_amd as sa
+    lib = _cabi.load()
+    q = torch.randn(1, 4, 1024, 128, device="cuda", dtype=torch.float16)
+    k, v = _mk(1, 4, 1024, 128, torch.float16, "HND", 5)
+    want = sa.sageattn(q, k, v, is_causal=False)
+    torch.cuda.synchronize()
+    sync = torch.empty(int(lib.sage_prepass_sync_words(1, 4)), dtype=torch.int32, device="cuda")
+    lib.sage_debug_prepass_fail(1)
+    try:
+        got = quant.prepass_kv_fp8(k, v, "HND", smooth_k=True, sync=sync)
+        torch.cuda.synchronize()
+        assert quant.prepass_failed_heads(sync, 1, 4) == 8                  # K and V entry of each of the 4 heads
+        assert torch.isnan(got[2]).all(), "k scales of a head that gave up must be NaN"
+        assert torch.isnan(got[4]).all(), "v scales of a head that gave up must be NaN"
+        assert (got[3].view(torch.uint8) == 0x7f).all(), "the V image of a head that gave up must be NaN bytes"
+        o = sa.sageattn(q, k, v, is_causal=False)
+        torch.cuda.synchronize()
+        assert torch.isnan(o.float()).all(), "attention over a poisoned pre-pass must be NaN, not a number"
+        old = quant._DEBUG
+        quant._DEBUG = True
+        try:
+            with pytest.raises(_cabi.SageKernelError):
+                quant.prepass_kv_fp8(k, v, "HND", smooth_k=True)
+        finally:
+            quant._DEBUG = old
+        # a single-slab head has no barrier and is unaffected
+        k1, v1 = _mk(1, 2, 300, 128, torch.float16, "HND", 6)
+        r1 = quant.prepass_kv_fp8(k1, v1, "HND", smooth_k=True)
+        assert torch.isfinite(r1[2]).all() and torch.isfinite(r1[4]).all()
+    finally:
+        lib.sage_debug_prepass_fail(0)
+    again = sa.sageattn(q, k, v, is_causal=False)
+    torch.cuda.synchronize()
+    assert torch.equal(again, want)
 
 
 @pytest.mark.parametrize("D,causal,layout,dtype,pv_accum,smooth_v,gqa", [
