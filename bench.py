@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- attention TFLOPS of the gfx950 SageAttention hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5] [--sweep] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5] [--sweep] [--no-sweep] [--no-cpu-baseline]
 
 Workload (default `c3` = BASELINE.json configs[2], the configuration the north-star target is
 quoted on): B=2, H=32, N=8192, D=128, causal, INT8 QK^T + FP8 PV with two-level FP32
@@ -202,15 +202,19 @@ def timed(fn, steps, warmup, dist_on, ramp_s=0.0):
 
 
 def cpu_baseline(cfg):
-    """The oracle (a straight CPU port of the reference algorithm) timed on this box's host cores on
-    a bounded sample of the same workload: same N, D, causal and precision, fewer (batch, head) units."""
+    """The oracle (a straight CPU port of the reference algorithm, OpenMP) timed on this box's host cores on a bounded
+    sample of the same workload: same N, D, mask and precision, a few (batch, head) units -- about 2-3 s, so that the
+    GPU phases are not a footnote of the run.  `reference_path`: the reference's OWN CPU-runnable path (its Triton kernels under
+    TRITON_INTERPRET=1), which cannot run on the GPU box (the reference is not there): the committed measurement of
+    tools/ref_cpu_time.py from the build container, cores stated."""
     import numpy as np
     import oracle
     oracle.build()
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     N, D = cfg["N"], cfg["D"]
-    H = max(4, min(cfg["B"] * cfg["H"], cores))        # ~10-30 s of CPU work at N=8192 on 8..256 cores
+    # one (batch, head) unit is ceil(N / 128) independent row blocks for the OpenMP loop; a few units keep every core busy
+    H = max(1, min(cfg["B"] * cfg["H"], max(1, cores // 32)))
     rng = np.random.default_rng(0)
     q8 = rng.integers(-95, 95, (1, H, N, D), dtype=np.int8)
     k8 = rng.integers(-95, 95, (1, H, N, D), dtype=np.int8)
@@ -228,9 +232,23 @@ def cpu_baseline(cfg):
     oracle.attn(q8, k8, v, qs, gq, ks, gk, causal=cfg["causal"], c=0.1275, pv_mode=mode, out_dtype=0, v_scale=vs)
     dt = time.perf_counter() - t0
     fl = 4.0 * H * N * N * D / (2 if cfg["causal"] else 1)
-    return {"value": round(fl / dt / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/sage_oracle.c orc_attn (OpenMP, {cores} threads): B=1 H={H} of the workload's "
-                      f"{cfg['B'] * cfg['H']} (batch,head) units, N={N} D={D} causal={cfg['causal']} pv={cfg['pv']}, {dt:.1f} s"}
+    out = {"value": round(fl / dt / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/sage_oracle.c orc_attn (OpenMP, {cores} threads): B=1 H={H} of the workload's "
+                     f"{cfg['B'] * cfg['H']} (batch,head) units, N={N} D={D} causal={cfg['causal']} pv={cfg['pv']}, {dt:.1f} s"}
+    ref = os.path.join(ROOT, "profiles", "ref_triton_cpu.json")
+    if os.path.exists(ref):
+        try:
+            with open(ref) as f:
+                r = json.load(f)
+            out["reference_path"] = {
+                "what": r.get("what"), "where": "build container (the reference is not on the GPU box); tools/ref_cpu_time.py -> profiles/ref_triton_cpu.json",
+                "cores": r.get("cores"), "cpu": r.get("cpu"),
+                "cases": [{"case": c["case"], "shape": c["shape"], "gflops": c["reference_triton_interpreter_gflops"],
+                           "seconds": c["reference_triton_interpreter_seconds"], "fp32_sdpa_cpu_gflops": c["fp32_sdpa_cpu_gflops"]}
+                          for c in r.get("cases", [])]}
+        except Exception as e:          # the artefact is informational
+            out["reference_path"] = {"error": repr(e)}
+    return out
 
 
 def accuracy(cfg, q, k, v):
@@ -330,7 +348,8 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=0.3,
                     help="untimed clock-ramp phase before the warmup steps (0 disables); reported in the JSON")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c4"])
-    ap.add_argument("--sweep", action="store_true", help="also print hd128 causal N=1k..32k kernel-only TFLOPS")
+    ap.add_argument("--sweep", action="store_true", help="also the reference bench scripts' batch 4 in the N=1k..32k kernel-only sweep")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the N=1k..32k kernel-only sweep that the default c3 run appends (BASELINE.json's metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replay", action="store_true", help="drop-in replay of the model's attention calls (use with --config c5)")
     ap.add_argument("--replay-layers", type=int, default=42)
@@ -350,6 +369,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    ranks_seen = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -357,6 +377,22 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # what this run really was: every rank reports the device it is bound to; rank 0 prints the list (and, over RCCL,
+        # insists on one distinct device per rank) so that a scaling record proves N ranks on N GPUs
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                "device_count": torch.cuda.device_count(), "name": torch.cuda.get_device_name(local_rank),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None),
+                "uuid": str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", "")), "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered}
+        try:
+            ranks_seen["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ranks_seen["rccl_version"] = None
+        if backend == "nccl":
+            devs = [(g["uuid"] or g["device"]) for g in gathered]
+            assert len(set(devs)) == world, f"ranks share a device: {devs}"
 
     from sageattention_amd import _cabi
     _cabi.load()
@@ -384,7 +420,11 @@ def main():
     prepass = prepass_roofline(cfg, k, v, args.config, between=lambda: kernel_only_step(cfg, ops, sm_scale))
 
     stats = torch.tensor([wall_k, wall_e], dtype=torch.float64, device=device)
+    per_rank_ms = None
     if dist_on:
+        allw = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allw, stats)
+        per_rank_ms = [round(t[0].item() / args.steps * 1e3, 4) for t in allw]
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     wall_k, wall_e = stats.tolist()
 
@@ -410,12 +450,16 @@ def main():
                      "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get(args.config),
                      "traffic_note": ("HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r2_run_m_pmc_*.txt), algorithmic %.4g" % ALGO_BYTES[args.config]) if args.config in PMC_TRAFFIC_BYTES else None,
                      "kernel": "sage_attn_kernel", "avg_launch_ms": round(kern_ms, 4),
+                     "algorithmic_flops_per_launch": fl,
                      "peak_note": "harmonic blend of the dense MFMA peaks of the two halves: INT8 5.0 POPS (QK^T) and " + ("FP8 5.0 PF (MX-scaled instruction)" if cfg["pv"] == "fp8" else "FP16 2.5 PF") + " (PV)"},
         "end_to_end": {"ms_per_call": round(wall_e / e2e_steps * 1e3, 4),
                        "tflops": round(fl * world / (wall_e / e2e_steps) / 1e12, 2),
                        "what": "sageattn(): K mean + INT8 Q/K quant + V pre-pass + attention",
                        "prepass": prepass},
     }
+    if ranks_seen is not None:
+        out["ranks_seen"] = ranks_seen
+        out["ms_per_step_per_rank"] = per_rank_ms
     if rank == 0:
         try:
             out["accuracy"] = accuracy(cfg, q, k, v)
@@ -423,10 +467,12 @@ def main():
             out["accuracy"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        if args.sweep:
-            # the config's batch (BASELINE.json: 2) and the reference bench scripts' default batch (4,
+        if (args.sweep or (args.config == "c3" and world == 1)) and not args.no_sweep:
+            # BASELINE.json's metric is the whole curve "hd=128 causal at N=1k..32k", so the default run carries it: kernel-only,
+            # the config's batch (2); --sweep adds the reference bench scripts' default batch (4,
             # bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7) -- 256 CUs need the larger grid at short sequences
-            for key, bsz in (("sweep_kernel_only_tflops", cfg["B_global"]), ("sweep_kernel_only_tflops_batch4", 4)):
+            batches = [("sweep_kernel_only_tflops", cfg["B_global"])] + ([("sweep_kernel_only_tflops_batch4", 4)] if args.sweep else [])
+            for key, bsz in batches:
                 sweep = {}
                 for n in (1024, 2048, 4096, 8192, 16384, 32768):
                     c = dict(CONFIGS[args.config], N=n, B=bsz)
@@ -436,6 +482,8 @@ def main():
                     sweep[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
                     del qq, kk, vv, oo
                 out[key] = sweep
+            out["sweep_note"] = ("kernel-only TFLOP/s of the workload's kernel at N = 1k .. 32k (B=%d, H=%d, D=%d, %s): 20 launches each, HIP events"
+                                 % (cfg["B_global"], CONFIGS[args.config]["H"], cfg["D"], "causal" if cfg["causal"] else "non-causal"))
         print(json.dumps(out))
     if dist_on:
         dist.barrier()
