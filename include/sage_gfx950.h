@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 11
+#define SAGE_ABI_VERSION 12
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -304,6 +304,13 @@ SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const
                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+/* The FP16-PV counterpart (sage_attn_fused_q_pv_f16 over a split key range; v_image is the fp16 image, no v_scale). */
+SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
+                                            const float *k_scale, const float *v_mean,
+                                            int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
 
 /* Merge a partial attention state into a running FP32 state by log-sum-exp (natural log), in place:
  *   m = max(lse_acc, lse_new); w_a = e^(lse_acc-m); w_b = e^(lse_new-m);

@@ -130,13 +130,15 @@ def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override:
     decode-like shapes) leave most of the 256 CUs idle.  Such a call runs as
     S chunks of Lk/S keys folded into the kv-head dimension and one merge by log-sum-exp.  Chunks are whole numbers of
     64-key tiles (the quantisation groups and the V image tiles are unchanged by the fold), so only S | Lk/64 is considered."""
-    if override == 0 or Lk % 64 != 0:
+    if override == 0:
+        return 0
+    if override:
+        if Lk % 64 != 0 or override < 2 or (Lk // 64) % override != 0:
+            raise ValueError(f"split_kv={override} must be >= 2 and divide the number of whole 64-key tiles (kv_len {Lk})")
+        return override
+    if Lk % 64 != 0:
         return 0
     ntk = Lk // 64
-    if override:
-        if override < 2 or ntk % override != 0:
-            raise ValueError(f"split_kv={override} must be >= 2 and divide the number of 64-key tiles ({ntk})")
-        return override
     n_wg = B * Hq * ((Lq + 127) // 128)
     if is_causal:
         # Causal calls are split only on request (split_kv=S; the mask then runs in global key coordinates).  Measured for the
@@ -163,7 +165,7 @@ def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_
     assert k_store.is_contiguous() and v_image.is_contiguous() and k_scale.is_contiguous()
     k_f = k_store.view(B, Hkv * S, Lc, D)
     ks_f = k_scale.view(B, Hkv * S, -1)
-    vs_f = v_scale.repeat_interleave(S, dim=1)
+    vs_f = None if v_scale is None else v_scale.repeat_interleave(S, dim=1)      # None: FP16 PV (fp16 V image)
     vm_f = None if v_mean is None else v_mean.repeat_interleave(S, dim=1)
     o_part = torch.empty((B, Hq * S, Lq, D), dtype=torch.float16, device=q.device)
     lse_part = torch.empty((B, Hq * S, Lq), dtype=torch.float32, device=q.device)
@@ -171,11 +173,18 @@ def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_
     _, _, _, _, p_sb, p_sh, p_sl = _dims(o_part, "HND")
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
     lib = _cabi.load()
-    rc = lib.sage_attn_fused_q_pv_f8_split(
-        _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
-        B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
-        int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
-    _cabi.check(rc, "sage_attn_fused_q_pv_f8_split")
+    if vs_f is None:
+        rc = lib.sage_attn_fused_q_pv_f16_split(
+            _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vm_f),
+            B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
+            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
+        _cabi.check(rc, "sage_attn_fused_q_pv_f16_split")
+    else:
+        rc = lib.sage_attn_fused_q_pv_f8_split(
+            _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
+            B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
+            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
+        _cabi.check(rc, "sage_attn_fused_q_pv_f8_split")
     o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
@@ -304,8 +313,17 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     return o[..., :head_dim_og]
 
 
-def _compiled_call(api, q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse):
-    """torch.compile route of the dense CUDA-named entry points: one opaque custom op around the eager pipeline (ops.py)."""
+_ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant")
+
+
+def _compiled_call(api, q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse,
+                   kwargs=None):
+    """torch.compile route of the dense CUDA-named entry points: one opaque custom op around the eager pipeline (ops.py).
+    The op takes the default routes; a route override (``split_kv`` / ``fused_prepass`` / ``fuse_q_quant``) cannot travel through
+    it, and a compiled run that silently took another route than the eager one would be a trap, so it is refused."""
+    given = [n for n in _ROUTE_KWARGS if kwargs and kwargs.get(n) is not None]
+    if given:
+        raise ValueError(f"{', '.join(given)}: route overrides are not supported under torch.compile (the compiled op takes the default routes)")
     o, lse = ops.sageattn_call(q, k, v, api, tensor_layout, bool(is_causal), qk_quant_gran,
                                None if sm_scale is None else float(sm_scale), pv_accum_dtype, bool(smooth_k), bool(smooth_v),
                                bool(return_lse))
@@ -388,7 +406,7 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
     straight into FP32; "fp16+fp32" keeps the reference's per-tile buffer structure (the tile
     buffer is FP32 here: CDNA4 MFMA has no FP16 accumulator); "fp16" maps to "fp32"."""
     if torch.compiler.is_compiling():
-        return _compiled_call("fp16", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse)
+        return _compiled_call("fp16", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse, kwargs)
     dtype = q.dtype
     _check_inputs(q, k, v)
     assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
@@ -415,8 +433,14 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
         v_image = prep_v_fp16(v, tensor_layout)
     if qk_quant_gran == "per_thread" and pv_accum_dtype != "fp16+fp32" and kwargs.get("fuse_q_quant", _FUSE_Q16_DEFAULT):
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM, one launch less)
-        o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
-                               return_lse, v_mean=vm)
+        B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
+        n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
+        if n_split:
+            o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
+                                         n_split, return_lse, v_mean=vm)
+        else:
+            o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
+                                   return_lse, v_mean=vm)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale)
     o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
@@ -433,7 +457,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
     keeps the full ``scale_max=448``; the reference's 2.25 is an FP16-accumulator artefact,
     core.py:805-807); "fp32" accumulates every tile straight into the output registers."""
     if torch.compiler.is_compiling():
-        return _compiled_call("fp8", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse)
+        return _compiled_call("fp8", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse, kwargs)
     dtype = q.dtype
     _check_inputs(q, k, v)
     assert qk_quant_gran in ["per_warp", "per_thread", "per_block"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."
@@ -484,7 +508,7 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_ca
     if pv_accum_dtype != "fp32+fp32":
         raise ValueError(f"Unsupported pv_accum_dtype: {pv_accum_dtype}")
     if torch.compiler.is_compiling():
-        return _compiled_call("sm90", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, False, return_lse)
+        return _compiled_call("sm90", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, False, return_lse, kwargs)
     dtype = q.dtype
     _check_inputs(q, k, v)
     assert qk_quant_gran in ["per_warp", "per_thread"], "qk_quant_gran must be either 'per_warp' or 'per_thread'."

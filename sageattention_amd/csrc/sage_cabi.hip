@@ -502,6 +502,21 @@ SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const
                           q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream);
 }
 
+SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
+                                            const float *k_scale, const float *v_mean,
+                                            int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
+    SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
+    SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);
+    return fused_q_common(q, k, v_image, o_part, lse_part, k_scale, nullptr, v_mean, B, Hq * kv_split, Hkv * kv_split, Lq, Lk_chunk, D,
+                          q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream,
+                          false);
+}
+
 SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,
                                int B, int H, int L, int D, int64_t n_sb, int64_t n_sh, int64_t n_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl, int dtype, int first, void *stream)
