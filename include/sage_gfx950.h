@@ -162,7 +162,7 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *         attention call that consumes the pre-pass returns NaN for the affected head instead of a plausible wrong number.
  *         sage_prepass_failed_heads(sync, B, H, stream) synchronises the stream and returns how many (K|V, b, h) entries
  *         carry the flag (0 = the launch was sound).
- *   L     at most sage_prepass_max_seqlen() (32768 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
+ *   L     at most sage_prepass_max_seqlen() (65536 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
  *         head wait for each other inside the launch, so all of them must fit on the device at once; longer
  *         sequences take the three-call sequence (SAGE_EINVAL here).  The bound uses the compute units `stream` may use
  *         (hipExtStreamGetCUMask).  Per head, ((ceil(L/512)*512 - 1) * row stride + D) * 2 must stay below 2^32.

@@ -372,6 +372,10 @@ def _fused_prepass_wanted(k, tensor_layout: str, override: Optional[bool]) -> bo
     if env in ("fused", "1"):
         return True
     B, H, L = _dims(k, tensor_layout)[:3]
+    if L > 32768:
+        # heads of 65 .. 128 slabs are within the barrier's reach (sage_prepass_max_seqlen = 65536) but every workgroup then waits for
+        # 128 others: 325 vs 311 us at B=1 H=16 N=65536 (profiles/r3_run_f_prepass_64k.txt) -- the sequence unless the caller insists
+        return False
     return L > 256 or B * H <= 256
 
 

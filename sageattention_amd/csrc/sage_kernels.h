@@ -113,7 +113,8 @@ struct PrepVParams {
 hipError_t launch_prep_v(const PrepVParams &p, hipStream_t stream);
 
 // ---- fused K / V pre-pass: one launch, one read of K and V (sage_prepass.hip) -----------------------------------------
-constexpr int kPrepassMaxSlabs = 32768 / kStatsSlab;   // slabs of one head that wait for each other inside the launch (L <= 32768)
+constexpr int kPrepassMaxSlabs = 65536 / kStatsSlab;   // slabs of one head that wait for each other inside the launch (L <= 65536):
+                                                       // 16 per XCD against 64 resident workgroup slots per XCD
 constexpr int kPrepassSyncStride = 32;  // uint32 words per (part, head): arrival + departure counter on their own 128-B line
 struct PrepassParams {
     const void *k;            // fp16 / bf16 [.., L, D] with strides (parts & 1)

@@ -14,7 +14,7 @@
 // Step 2 is a per-head barrier between workgroups of one launch.  It is safe because (a) gfx950 hands workgroups to
 // its 8 XCDs round-robin and each XCD starts its share in index order, (b) the slabs of a head are consecutive in
 // index, so the lowest unfinished head always has every slab resident or next in line, and (c) the C ABI refuses
-// heads of more than kPrepassMaxSlabs slabs (8 per XCD) or than the device has CUs, far below the resident-workgroup
+// heads of more than kPrepassMaxSlabs slabs (16 per XCD) or than the device has CUs, far below the resident-workgroup
 // capacity (2 per CU).
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.

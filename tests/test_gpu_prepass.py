@@ -51,7 +51,9 @@ CASES = [  # B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran
     (1, 2, 3000, 128, torch.bfloat16, "HND", True, False, 128, "per_thread"),     # the sm90 entry point's 128-key groups
     (2, 2, 640, 64, torch.float16, "HND", True, False, 128, "per_warp"),
     (1, 2, 2048, 128, torch.bfloat16, "HND", False, False, 64, "per_thread"),     # smooth_k off: no statistics for K
-    (1, 1, 32768, 128, torch.bfloat16, "HND", True, True, 64, "per_thread"),      # 64 slabs: the longest head
+    (1, 1, 32768, 128, torch.bfloat16, "HND", True, True, 64, "per_thread"),      # 64 slabs
+    (1, 2, 65536, 128, torch.float16, "HND", True, True, 64, "per_thread"),       # 128 slabs: the longest head the barrier takes
+    (1, 1, 65536 - 300, 64, torch.bfloat16, "NHD", True, False, 64, "per_warp"),
     (1, 2, 1, 64, torch.float16, "HND", True, True, 64, "per_thread"),
 ]
 
@@ -95,7 +97,7 @@ def test_many_small_heads_and_full_chip():
 
 
 def test_too_long_is_refused():
-    k = torch.zeros(1, 1, 32768 + 512, 64, device="cuda", dtype=torch.float16)
+    k = torch.zeros(1, 1, 65536 + 512, 64, device="cuda", dtype=torch.float16)
     assert not quant.prepass_fused_ok(k)
     with pytest.raises(ValueError, match="too long"):
         quant.prepass_kv_fp8(k, k)
@@ -157,8 +159,8 @@ def test_default_prepass_choice():
     assert core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", None)
     assert core._fused_prepass_wanted(mk(1, 4, 200, 64), "HND", None)            # few heads: one launch instead of six
     assert not core._fused_prepass_wanted(mk(64, 16, 256, 64), "HND", None)      # many half-empty slabs
-    assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", None)      # beyond the in-launch barrier's reach
-    assert not core._fused_prepass_wanted(mk(1, 2, 40000, 64), "HND", True)
+    assert not core._fused_prepass_wanted(mk(1, 2, 70000, 64), "HND", None)      # beyond the in-launch barrier's reach
+    assert not core._fused_prepass_wanted(mk(1, 2, 70000, 64), "HND", True)
     assert not core._fused_prepass_wanted(mk(2, 32, 8192, 128), "HND", False)
 
 
