@@ -64,6 +64,9 @@
 #ifndef SAGE_PLAIN_PV   // pipelined FP8 loop: v_mfma_f32_32x32x64_f8f6f4 instead of its block-scaled form with unit scales
 #define SAGE_PLAIN_PV 1
 #endif
+#ifndef SAGE_GRP4       // experiment: the FP8 pipelined loop's softmax in statements of four scores
+#define SAGE_GRP4 1
+#endif
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
@@ -922,6 +925,45 @@ sage_attn_kernel(const AttnParams p)
                         const v4u b = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
                         vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
                     };
+#if SAGE_GRP4
+                    // experiment: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
+                    // can sit between the exponentials and the adds
+                    float u0, u1, u2, u3;
+                    auto g4a = [&](int w) {
+                        const int sb = w >> 2, i0 = 4 * (w & 3);
+                        asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
+                                     "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
+                                     "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
+                                     "v_fma_f32 %2, %2, %9, -%10\n\tv_fma_f32 %3, %3, %9, -%10\n\t"
+                                     "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"
+                                     : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(m_new));
+                    };
+                    auto g4b = [&](int w) {
+                        asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
+                                     "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
+                                     : "+v"(rs0), "+v"(rs1), "+v"(pc[w])
+                                     : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+                    };
+                    if constexpr (C::DT == 4) {
+                        A_PV(o[2], vf[2], pp, e8m0);
+                        g4a(0); g4b(0);
+                        A_PV(o[3], vf[3], pp, e8m0);
+                        g4a(1); g4b(1);
+                        qk_next(0, 0); g4a(2);
+                        qk_next(0, 1); g4b(2); g4a(3);
+                        qk_next(0, 2); g4b(3);
+                        qk_next(0, 3); g4a(4);
+                        A_FENCE(); read_v(0); read_v(1); A_FENCE();
+                        g4b(4);
+                        qk_next(1, 0); g4a(5);
+                        qk_next(1, 1); g4b(5); g4a(6);
+                        qk_next(1, 2); g4b(6);
+                        qk_next(1, 3);
+                        A_FENCE(); read_v(2); read_v(3); A_FENCE();
+                        g4a(7); g4b(7);
+                    } else
+#endif
                     if constexpr (C::DT == 4) {
                         A_PV(o[2], vf[2], pp, e8m0);
                         grp(0); grp(1);
