@@ -539,7 +539,10 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 }
 
 template <int D, int DT>
-__global__ void __launch_bounds__(kPrepassThreads, 4)
+#ifndef SAGE_PP_WAVES      // waves per SIMD the allocator must allow (4 = two 512-thread workgroups per CU)
+#define SAGE_PP_WAVES 4
+#endif
+__global__ void __launch_bounds__(kPrepassThreads, SAGE_PP_WAVES)
 prepass_kv_kernel(const PrepassParams p)
 {
     __shared__ PrepassLds<D> lds;

@@ -169,6 +169,51 @@ def attn_fp8(q8, k8, v8, q_scale, q_slot, k_scale, k_slot, v_scale, v_mean, *, c
     return o, lse
 
 
+def attn_f16(q8, k8, vh, q_scale, q_slot, k_scale, k_slot, *, causal: bool, sm_scale: float, out_dtype: torch.dtype):
+    """The FP16-PV CUDA kernels (csrc/qattn/qk_int_sv_f16_cuda_sm80.cu:46-671, accum_f32 form) for one (batch, head): no exp offset
+    (`update_mdo<..., exp_offset = false>`, :303), P rounded to fp16 by RS_32_to_16 (:316-317), and -- the point of this restatement --
+    the denominator accumulated by the TENSOR CORE from those rounded halves (`accumulate_d<..., kTensorCore>` -> mma::rowsum_f16f16f32,
+    :313-320, attn_utils.cuh:529-545; DenominatorAccumUnit = kTensorCore in every instantiation :814,989,1164,1348): an FP32 sum of fp16(P).
+    vh [Lk, D] float16.  Returns (o [Lq, D] out_dtype, lse [Lq] fp32 in log2 units)."""
+    Lq, D = q8.shape
+    Lk = k8.shape[0]
+    sm = torch.tensor(sm_scale, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32)
+    vf = vh.float()
+    o = torch.empty(Lq, D, dtype=out_dtype)
+    lse = torch.empty(Lq, dtype=torch.float32)
+    for r0 in range(0, Lq, CTA_Q):
+        rows = min(CTA_Q, Lq - r0)
+        qi = q8[r0:r0 + rows].double()
+        qs = q_scale[q_slot[r0:r0 + rows]]
+        m = torch.full((rows,), -5000000.0)
+        d = torch.ones(rows)
+        RO = torch.zeros(rows, D)
+        kend = min(Lk, r0 + CTA_Q) if causal else Lk
+        for n0 in range(0, kend, CTA_K):
+            nk = min(CTA_K, Lk - n0)
+            S = (qi @ k8[n0:n0 + nk].double().T).float()
+            scale = sm * (qs[:, None] * k_scale[k_slot[n0:n0 + nk]][None, :])
+            keep = torch.ones(rows, nk, dtype=torch.bool)
+            if causal:
+                keep = (n0 + torch.arange(nk))[None, :] <= (r0 + torch.arange(rows))[:, None]
+            m_temp = torch.where(keep, _fma32(S, scale, 0.0), torch.tensor(-float("inf"))).amax(dim=1)     # max(RS) * sm_scale
+            m_new = torch.maximum(m, m_temp)
+            o_scale = _exp2_32(m - m_new)
+            P = torch.where(keep, _exp2_32(_fma32(S, scale, -m_new[:, None])), torch.tensor(0.0))
+            P16 = P.to(torch.float16).float()                # RS_32_to_16
+            rs = torch.zeros(rows)
+            for j in range(nk):                              # the tensor core's FP32 accumulation of the fp16 P
+                rs = rs + P16[:, j]
+            d = d * o_scale + rs
+            RO = RO * o_scale[:, None]
+            for j in range(nk):
+                RO = RO + P16[:, j:j + 1] * vf[n0 + j][None, :]
+            m = m_new
+        o[r0:r0 + rows] = (RO / d[:, None]).to(out_dtype)
+        lse[r0:r0 + rows] = torch.log2(d) + m
+    return o, lse
+
+
 def sageattn_fp8_cuda(q, k, v, *, is_causal: bool, qk_quant_gran: str, smooth_k: bool = True, smooth_v: bool = False,
                       pv_accum_dtype: str = "fp32+fp32", sm_scale: float | None = None):
     """sageattn_qk_int8_pv_fp8_cuda (core.py:636-826) on HND CPU tensors [B,H,L,D] (D in {64,128}), restated end to end.

@@ -86,3 +86,34 @@ def test_smooth_v_padding_zeros_enter_the_statistics():
     assert np.array_equal(v8[0, 0], t8.view(torch.uint8).numpy())
     # mean = 5 * 21/32; the padding zeros sit |mean| ~ 3.3 away, the real tokens only ~1.7: amax must be the former
     assert np.all(vs[0, 0] * 448.0 > 3.0)
+
+
+@pytest.mark.parametrize("Lq,Lk,D,dtype,causal,gran", [(200, 333, 64, torch.float16, False, "per_warp"), (150, 150, 128, torch.bfloat16, True, "per_thread"),
+                                                     (129, 700, 128, torch.float16, False, "per_thread")])
+def test_fp16_pv_cuda_form_denominator_sums_the_rounded_p(Lq, Lk, D, dtype, causal, gran):
+    """oracle pv_mode 1 (the FP16-PV CUDA kernels) against the torch restatement of qk_int_sv_f16_cuda_sm80.cu: the softmax
+    denominator is the FP32 sum of the fp16-ROUNDED probabilities (tensor-core row sum, sm80.cu:313-320).  The Lk = 333 / per-warp
+    case is the one where an implementation that drops fp16-subnormal P from the sum is 0.6-1.7 % off (profiles/r3_run_d_*): the two
+    restatements must agree to the last output ulp, and both must differ measurably from the sum of the un-rounded P."""
+    q = _mk((1, 1, Lq, D), dtype, 11)
+    k = _mk((1, 1, Lk, D), dtype, 12, bias=3.0)
+    v = _mk((1, 1, Lk, D), dtype, 13)
+    code = oracle.F16 if dtype == torch.float16 else oracle.BF16
+    o_c, lse_c, aux = oracle.sageattn_dense(_bits(q), _bits(k), _bits(v), code, is_causal=causal, qk_quant_gran=gran, pv="f16",
+                                            return_lse=True, smooth_k=True)
+    gq, gk = torch.from_numpy(aux["gq"].astype("int64")), torch.from_numpy(aux["gk"].astype("int64"))
+    vh = v[0, 0].to(torch.float16)
+    o_t, lse_t = ref.attn_f16(torch.from_numpy(aux["q8"][0, 0]), torch.from_numpy(aux["k8"][0, 0]), vh,
+                              torch.from_numpy(aux["qs"][0, 0]), gq, torch.from_numpy(aux["ks"][0, 0]), gk,
+                              causal=causal, sm_scale=D ** -0.5, out_dtype=dtype)
+    got, want = o_c[0, 0].astype(np.int32), _bits(o_t).astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3, (int(diff.max()), float((diff != 0).mean()))
+    # the raw log-sum-exp of the kernel (log2 units, before the host's q.km correction): recompute it from the oracle's pieces
+    o_raw, lse_raw = oracle.attn(aux["q8"], aux["k8"], _bits(vh)[None, None], aux["qs"], aux["gq"], aux["ks"], aux["gk"], causal=causal,
+                                 c=aux["c"], pv_mode=oracle.PV_F16_F32ACC, out_dtype=code, return_lse=True)
+    assert np.abs(lse_raw[0, 0] - lse_t.numpy()).max() < 2e-6 * max(1.0, float(np.abs(lse_t.numpy()).max()))
+    # and the Triton form (un-rounded sum) is a different number: the two modes are told apart by their denominators
+    _, lse_tr = oracle.attn(aux["q8"], aux["k8"], _bits(vh)[None, None], aux["qs"], aux["gq"], aux["ks"], aux["gk"], causal=causal,
+                            c=aux["c"], pv_mode=oracle.PV_F16_TRITON, out_dtype=code, return_lse=True)
+    assert np.abs(lse_tr[0, 0] - lse_raw[0, 0]).max() > 1e-6
