@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 12
+#define SAGE_ABI_VERSION 13
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -71,12 +71,20 @@ SAGE_API int sage_abi_version(void);
 SAGE_API const char *sage_last_error(void);
 
 /* Kernel route of the dense FP8-PV, head_dim 128 attention entry points (sage_attn_qk_int8_pv_f8, sage_attn_fused_q_pv_f8).
- * -1 (default): by shape -- calls with more than 128 query rows per head run the 256-row workgroup kernel (one wave per SIMD,
- * sage_attn64.hip), the rest the 128-row kernel; 0: always the 128-row kernel; 1: the 256-row kernel wherever it is eligible.
+ * -1 (default): by shape -- today always the 128-row kernel (the 256-row workgroup kernel, one wave per SIMD, sage_attn64.hip,
+ * measured 12-17 % slower at every size); 0: always the 128-row kernel; 1: the 256-row kernel wherever it is eligible.
  * Both kernels implement the same reference kernels (csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:46-704) with the same operand
  * order; the switch exists for A/B measurements and tests.  Process-wide; initialised from the environment variable SAGE_ATTN64. */
 SAGE_API int sage_attn64_mode(void);
 SAGE_API void sage_set_attn64_mode(int mode);
+
+/* Work order of causal dense launches of the 128-row kernels (which (head, query block) item workgroup blockIdx takes; results do
+ * not depend on it).  -1 (default): heads in groups sized by the grid, longest query blocks of a group first, single-round grids
+ * folded so that a CU's two workgroups are a long and a short block; 0: head-major, longest block of each head first (rounds 1-2);
+ * n > 0: groups of n heads.  The reference launches blockIdx.x = query block in ascending order (qk_int_sv_f8_cuda_sm89.cuh:720-738)
+ * and leaves the order to the hardware.  Process-wide; initialised from the environment variable SAGE_ORDER_GROUP. */
+SAGE_API int sage_work_order(void);
+SAGE_API void sage_set_work_order(int group);
 
 /* Size in bytes of the tiled V^T image for `n_kv_tiles_total` 64-token tiles (all batches, heads). */
 SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total);

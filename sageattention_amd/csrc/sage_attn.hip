@@ -67,6 +67,9 @@
 #ifndef SAGE_GRP4       // experiment: the FP8 pipelined loop's softmax in statements of four scores
 #define SAGE_GRP4 1
 #endif
+#ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
+#define SAGE_ORDER_DEFAULT -1
+#endif
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
@@ -169,7 +172,22 @@ sage_attn_kernel(const AttnParams p)
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
         const int nwg = gridDim.x;
         const int qq = nwg >> 3, rr = nwg & 7;
-        const int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        if (CAUSAL && p.order_group > 0) {
+            // causal work order inside the XCD's run of whole heads (set_work_order below): heads in groups of `order_group`, inside a
+            // group longest query block first ACROSS its heads, so the run ends on the group's shortest blocks instead of on one head's
+            // longest; a grid that fits the XCD's resident slots in one round is folded, so that the two workgroups the dispatcher
+            // puts on one CU (in-XCD indices i and i + 32, tools/microbench/ubench7_dispatch.hip) are the i-th longest and the
+            // i-th shortest
+            int r = idx;
+            if (p.order_fold != 0 && idx >= 32) r = qq - 1 - (idx - 32);
+            const int gsz = p.order_group * nqblk;
+            const int gi = r / gsz, within = r - gi * gsz;
+            const int hpx = qq / nqblk;
+            const int gc = (hpx - gi * p.order_group) < p.order_group ? (hpx - gi * p.order_group) : p.order_group;
+            const int qrank = within / gc, hh = within - qrank * gc;
+            wid = xcd * qq + (gi * p.order_group + hh) * nqblk + qrank;
+        }
         const int bh = wid / nqblk;
         qblk = nqblk - 1 - (wid - bh * nqblk);
         b = bh / p.Hq;
@@ -1461,9 +1479,44 @@ static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
     return false;
 }
 
-// per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
-hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
+// Causal dense grids: the order in which an XCD's workgroups take its (head, query block) items (see the kernel's work-item mapping).
+// Every XCD must own whole heads (B * Hq a multiple of 8); otherwise, and for split-KV chunks (weights depend on the chunk), the
+// head-major heavy-first order stays.  Group size: the last group's work has to cover its own longest block on all resident slots,
+// G * nqblk * (nqblk + 1) / slots >= 2 * nqblk, or the launch ends on a tail of one head's long blocks; twice that measured best
+// (profiles/r3_run_j_work_order_ab.txt: N=8k prefers 2-4 heads -- eight spread the XCD's L2 over 16 MB of K/V --, N<=4k all eight).
+// SAGE_ORDER_GROUP = 0 restores the head-major order, n > 0 forces the group size (experiments).
+static int g_work_order = -2;         // -2: not read yet
+int work_order()
 {
+    if (g_work_order == -2) {
+        const char *e = getenv("SAGE_ORDER_GROUP");
+        g_work_order = (e != nullptr && e[0] != 0) ? atoi(e) : SAGE_ORDER_DEFAULT;
+    }
+    return g_work_order;
+}
+void set_work_order_mode(int group) { g_work_order = group; }
+static void set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
+{
+    q.order_group = 0;
+    q.order_fold = 0;
+    if (!causal || masked || q.cu_q != nullptr || q.kv_split > 1 || q.nqblk <= 1 || ((q.B * q.Hq) & 7) != 0) return;
+    const int forced = work_order();
+    if (forced == 0) return;
+    const int hpx = q.B * q.Hq / 8;
+    const int wg_per_cu = head_dim == 64 ? 3 : 2;                 // SAGE_MIN_WAVES
+    const int slots = 32 * wg_per_cu;
+    int grp = forced > 0 ? forced : (4 * slots + q.nqblk) / (q.nqblk + 1);
+    grp = grp < 1 ? 1 : (grp > hpx ? hpx : grp);
+    q.order_group = grp;
+    const int cnt = hpx * q.nqblk;
+    q.order_fold = (wg_per_cu == 2 && cnt > 32 && cnt <= 64) ? 1 : 0;
+}
+
+// per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
+hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
+{
+    AttnParams p = p_in;
+    set_work_order(p, causal, head_dim, false);
     const int nwork = p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
@@ -1476,9 +1529,11 @@ hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, i
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
+hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool causal, bool kthread,
                        bool two_level, int mask_kind, hipStream_t stream)
 {
+    AttnParams p = p_in;
+    set_work_order(p, causal, head_dim, mask_kind != 0);
     // varlen grids are padded to whole rounds of 8 (sequence, kv-head) units, see the work-item mapping
     const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : p.B * p.Hq * p.nqblk;
     if (nwork <= 0) return hipSuccess;

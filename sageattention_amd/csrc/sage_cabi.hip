@@ -111,6 +111,8 @@ SAGE_API int sage_abi_version(void) { return SAGE_ABI_VERSION; }
 SAGE_API const char *sage_last_error(void) { return g_err; }
 SAGE_API int sage_attn64_mode(void) { return sage::attn64_mode(); }
 SAGE_API void sage_set_attn64_mode(int mode) { sage::set_attn64_mode(mode < -1 ? -1 : (mode > 1 ? 1 : mode)); }
+SAGE_API int sage_work_order(void) { return sage::work_order(); }
+SAGE_API void sage_set_work_order(int group) { sage::set_work_order_mode(group < -1 ? -1 : group); }
 
 SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total)
 {

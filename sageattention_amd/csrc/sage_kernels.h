@@ -39,6 +39,8 @@ struct AttnParams {
     int out_dtype;            // DT_F16 / DT_BF16
     long lse_sh;              // varlen lse head stride (unused for dense)
     float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain
+    int order_group;          // set by the launchers (sage_attn.hip set_work_order): causal dense work order, heads per group; 0 = head-major
+    int order_fold;           // 1: single-round grid, pair the i-th longest with the i-th shortest block on a CU
 };
 
 // mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)
@@ -54,6 +56,9 @@ hipError_t launch_attn64(const AttnParams &p, int head_dim, bool causal, bool kt
 // (sage_attn64.hip) wherever it is eligible.  Initialised from the environment variable SAGE_ATTN64; tests and benchmarks set it.
 int attn64_mode();
 void set_attn64_mode(int mode);
+// causal dense work order of the 128-row kernels: -1 grouped / folded by grid size, 0 head-major, n groups of n heads (SAGE_ORDER_GROUP)
+int work_order();
+void set_work_order_mode(int group);
 
 // ---- INT8 quantisation of Q / K ----------------------------------------------------------------
 enum : int { QS_TRITON = 0, QS_CUDA = 1, QS_TRITON_THREAD = 2 };          // rounding / epsilon style

@@ -113,3 +113,32 @@ def test_results_do_not_depend_on_what_the_allocator_hands_out(route, case):
         got = fn(q, k, v, **kw)
         torch.cuda.synchronize()
         assert torch.equal(got, want), f"{name}: the result depends on stale memory ({'NaN' if fill is not None else '0x5A'} fill)"
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 32, 32, 1024, 128),     # 64 items per XCD: one round, folded (a long and a short block per CU)
+    (1, 8, 8, 6144, 128),       # 48 items per XCD, one head: folded, partial second half
+    (1, 8, 2, 3968, 128),       # 31 items per XCD: one workgroup per CU, no fold
+    (2, 8, 8, 2048, 128),       # two heads per XCD, several rounds
+    (1, 24, 24, 1500, 64),      # D=64 (three workgroups per CU), three heads per XCD, ragged last block
+    (1, 16, 16, 777, 128),      # ragged
+], ids=lambda s: "b%dh%dk%dn%dd%d" % s)
+def test_causal_work_order_does_not_change_a_bit(route, shape):
+    """The causal launches pick which (head, query block) a workgroup takes from blockIdx (grouped / folded by grid size,
+    sage_set_work_order); every order must be a permutation of the same work: outputs and LSE bit-equal to the head-major order."""
+    B, Hq, Hkv, N, D = shape
+    q, k, v = _qkv(B, Hq, Hkv, N, N, D, BF16, seed=N)
+    old = route.sage_work_order()
+    try:
+        outs = {}
+        for order in (0, -1, 1, 3, 5, 64):
+            route.sage_set_work_order(order)
+            o, lse = sa.sageattn(q, k, v, is_causal=True, return_lse=True)
+            o2 = sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=True, qk_quant_gran="per_warp", pv_accum_dtype="fp32")
+            torch.cuda.synchronize()
+            outs[order] = (o, lse, o2)
+        assert torch.isfinite(outs[0][0].float()).all()
+        for order, (o, lse, o2) in outs.items():
+            assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1]) and torch.equal(o2, outs[0][2]), f"order {order} differs"
+    finally:
+        route.sage_set_work_order(old)
