@@ -174,19 +174,32 @@ sage_attn_kernel(const AttnParams p)
         const int qq = nwg >> 3, rr = nwg & 7;
         int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
         if (CAUSAL && p.order_group > 0) {
-            // causal work order inside the XCD's run of whole heads (set_work_order below): heads in groups of `order_group`, inside a
-            // group longest query block first ACROSS its heads, so the run ends on the group's shortest blocks instead of on one head's
-            // longest; a grid that fits the XCD's resident slots in one round is folded, so that the two workgroups the dispatcher
-            // puts on one CU (in-XCD indices i and i + 32, tools/microbench/ubench7_dispatch.hip) are the i-th longest and the
-            // i-th shortest
+            // Causal work order (set_work_order below).  B * Hq = 8 * hq + R heads: every XCD owns hq whole heads; the R left-over
+            // heads are dealt to all eight XCDs by query block (octets of blocks, boustrophedon, so every XCD gets the same mix of
+            // long and short ones).  The XCD's list: the left-over heads' blocks first, then its own heads in groups of
+            // `order_group`; inside a group longest query block first ACROSS the heads, so the run ends on the shortest blocks of
+            // several heads instead of on one head's longest.  A grid that fits the XCD's resident slots in one round is folded, so
+            // that the two workgroups the dispatcher puts on one CU (in-XCD indices i and i + 32, tools/microbench/
+            // ubench7_dispatch.hip) are the i-th longest and the i-th shortest.
             int r = idx;
             if (p.order_fold != 0 && idx >= 32) r = qq - 1 - (idx - 32);
-            const int gsz = p.order_group * nqblk;
-            const int gi = r / gsz, within = r - gi * gsz;
-            const int hpx = qq / nqblk;
-            const int gc = (hpx - gi * p.order_group) < p.order_group ? (hpx - gi * p.order_group) : p.order_group;
-            const int qrank = within / gc, hh = within - qrank * gc;
-            wid = xcd * qq + (gi * p.order_group + hh) * nqblk + qrank;
+            const int nleft = p.order_left, hpx = (p.B * p.Hq) >> 3;
+            const int left_cnt = nleft * ((nqblk + 7) >> 3);
+            int head, qrank;
+            if (r < left_cnt) {
+                const int oct = r / nleft;
+                head = r - oct * nleft;
+                qrank = 8 * oct + ((oct & 1) ? 7 - xcd : xcd);
+                if (qrank >= nqblk) return;
+            } else {
+                r -= left_cnt;
+                const int gsz = p.order_group * nqblk;
+                const int gi = r / gsz, within = r - gi * gsz;
+                const int gc = (hpx - gi * p.order_group) < p.order_group ? (hpx - gi * p.order_group) : p.order_group;
+                qrank = within / gc;
+                head = nleft + xcd * hpx + gi * p.order_group + (within - qrank * gc);
+            }
+            wid = head * nqblk + qrank;
         }
         const int bh = wid / nqblk;
         qblk = nqblk - 1 - (wid - bh * nqblk);
@@ -1479,9 +1492,9 @@ static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
     return false;
 }
 
-// Causal dense grids: the order in which an XCD's workgroups take its (head, query block) items (see the kernel's work-item mapping).
-// Every XCD must own whole heads (B * Hq a multiple of 8); otherwise, and for split-KV chunks (weights depend on the chunk), the
-// head-major heavy-first order stays.  Group size: the last group's work has to cover its own longest block on all resident slots,
+// Causal dense grids: the order in which an XCD's workgroups take (head, query block) items (see the kernel's work-item mapping).
+// Returns the grid size.  Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first
+// order over contiguous runs.  Group size: the last group's work has to cover its own longest block on all resident slots,
 // G * nqblk * (nqblk + 1) / slots >= 2 * nqblk, or the launch ends on a tail of one head's long blocks; twice that measured best
 // (profiles/r3_run_j_work_order_ab.txt: N=8k prefers 2-4 heads -- eight spread the XCD's L2 over 16 MB of K/V --, N<=4k all eight).
 // SAGE_ORDER_GROUP = 0 restores the head-major order, n > 0 forces the group size (experiments).
@@ -1495,29 +1508,34 @@ int work_order()
     return g_work_order;
 }
 void set_work_order_mode(int group) { g_work_order = group; }
-static void set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
+static int set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
 {
     q.order_group = 0;
     q.order_fold = 0;
-    if (!causal || masked || q.cu_q != nullptr || q.kv_split > 1 || q.nqblk <= 1 || ((q.B * q.Hq) & 7) != 0) return;
+    q.order_left = 0;
+    const int nheads = q.B * q.Hq;
+    if (q.cu_q != nullptr) return ((q.B * q.Hkv + 7) / 8) * 8 * q.group * q.nqblk;   // varlen: whole rounds of 8 (sequence, kv-head) units
     const int forced = work_order();
-    if (forced == 0) return;
-    const int hpx = q.B * q.Hq / 8;
+    if (!causal || masked || q.kv_split > 1 || q.nqblk <= 1 || forced == 0) return nheads * q.nqblk;
+    const int hpx = nheads / 8, left = nheads % 8;
     const int wg_per_cu = head_dim == 64 ? 3 : 2;                 // SAGE_MIN_WAVES
     const int slots = 32 * wg_per_cu;
     int grp = forced > 0 ? forced : (4 * slots + q.nqblk) / (q.nqblk + 1);
-    grp = grp < 1 ? 1 : (grp > hpx ? hpx : grp);
+    grp = grp > hpx ? hpx : grp;
+    grp = grp < 1 ? 1 : grp;
     q.order_group = grp;
-    const int cnt = hpx * q.nqblk;
-    q.order_fold = (wg_per_cu == 2 && cnt > 32 && cnt <= 64) ? 1 : 0;
+    q.order_left = left;
+    const int cnt = left * ((q.nqblk + 7) / 8) + hpx * q.nqblk;
+    const bool one_sorted_list = (left == 0 && grp >= hpx) || hpx == 0;
+    q.order_fold = (wg_per_cu == 2 && cnt > 32 && cnt <= 64 && one_sorted_list) ? 1 : 0;
+    return 8 * cnt;
 }
 
 // per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
 hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
 {
     AttnParams p = p_in;
-    set_work_order(p, causal, head_dim, false);
-    const int nwork = p.B * p.Hq * p.nqblk;
+    const int nwork = set_work_order(p, causal, head_dim, false);
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
     if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, true, q_dtype == DT_F16 ? 1 : 2, stream);
@@ -1533,9 +1551,7 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
                        bool two_level, int mask_kind, hipStream_t stream)
 {
     AttnParams p = p_in;
-    set_work_order(p, causal, head_dim, mask_kind != 0);
-    // varlen grids are padded to whole rounds of 8 (sequence, kv-head) units, see the work-item mapping
-    const int nwork = p.cu_q != nullptr ? ((p.B * p.Hkv + 7) / 8) * 8 * p.group * p.nqblk : p.B * p.Hq * p.nqblk;
+    const int nwork = set_work_order(p, causal, head_dim, mask_kind != 0);
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
         if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)

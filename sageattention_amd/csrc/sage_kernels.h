@@ -41,6 +41,7 @@ struct AttnParams {
     float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain
     int order_group;          // set by the launchers (sage_attn.hip set_work_order): causal dense work order, heads per group; 0 = head-major
     int order_fold;           // 1: single-round grid, pair the i-th longest with the i-th shortest block on a CU
+    int order_left;           // (B * Hq) % 8 heads whose query blocks are dealt to all eight XCDs
 };
 
 // mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)

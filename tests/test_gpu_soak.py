@@ -122,6 +122,10 @@ def test_results_do_not_depend_on_what_the_allocator_hands_out(route, case):
     (2, 8, 8, 2048, 128),       # two heads per XCD, several rounds
     (1, 24, 24, 1500, 64),      # D=64 (three workgroups per CU), three heads per XCD, ragged last block
     (1, 16, 16, 777, 128),      # ragged
+    (1, 12, 12, 2048, 128),     # 12 heads: one whole head per XCD + four left-over heads dealt to all XCDs by query block
+    (1, 4, 4, 16384, 128),      # fewer heads than XCDs: every head dealt by query block, 64 items per XCD, folded
+    (1, 28, 4, 1100, 128),      # GQA, 3 whole + 4 left-over heads, 9 blocks (ragged octet: empty workgroups exit)
+    (1, 7, 7, 1300, 64),        # D=64, left-over heads only
 ], ids=lambda s: "b%dh%dk%dn%dd%d" % s)
 def test_causal_work_order_does_not_change_a_bit(route, shape):
     """The causal launches pick which (head, query block) a workgroup takes from blockIdx (grouped / folded by grid size,
