@@ -371,9 +371,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     row_values(i, f);
                     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
                 } else {
-                    // values rounded to the input dtype (quant_per_block.py:53-54): the word is overwritten with the smoothed,
-                    // rounded pair (pass 2 only unpacks it) and the abs-max runs on the 16-bit patterns, which order like
-                    // unsigned integers in a sign-magnitude format
+                    // values rounded to the input dtype (quant_per_block.py:53-54): the smoothed, rounded pair is formed in a
+                    // temporary (rw keeps the raw word; pass 2 recomputes the pair) and the abs-max runs on the 16-bit
+                    // patterns, which order like unsigned integers in a sign-magnitude format
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         unsigned u = rw[i][c];
