@@ -61,6 +61,7 @@ CONFIGS = {
     "n1k": dict(B=2, H=32, Hkv=32, N=1024, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=1024"),
     "n2k": dict(B=2, H=32, Hkv=32, N=2048, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=2048"),
     "n4k": dict(B=2, H=32, Hkv=32, N=4096, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=4096"),
+    "n16k": dict(B=2, H=32, Hkv=32, N=16384, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=16384"),
     "h4": dict(B=1, H=4, Hkv=4, N=16384, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=4 N=16384 causal"),
 }
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: bf16/f16 2.5 PF, fp8 5.0 PF (the MX-scaled
@@ -68,8 +69,10 @@ CONFIGS = {
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
 # HBM bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-# gfx950 correction per MI355X_MICROARCH.md); see profiles/r2_run_m_pmc_c3.txt (FETCH_SIZE / WRITE_SIZE are in KiB: c3 = (2 x 105481 + 131072) KiB), _c5, _c2
-PMC_TRAFFIC_BYTES = {"c3": 350.2e6, "c5": 602.4e6, "c2": 205.2e6}
+# gfx950 correction per MI355X_MICROARCH.md).  c3 / c2: profiles/r3_run_k_order_traffic.txt (FETCH_SIZE / WRITE_SIZE are in KiB: c3 = (2 x 147446 +
+# 131072) KiB, c2 = (2 x 111159 + 65536) KiB with the round-3 causal work order, whose groups of heads share an XCD's L2: round 2's head-major
+# order moved 350.2e6 / 205.2e6 and was 5-15 % slower); c5 (non-causal, order unchanged): profiles/r2_run_m_pmc_c5.txt
+PMC_TRAFFIC_BYTES = {"c3": 436.2e6, "c5": 602.4e6, "c2": 294.8e6}
 ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6}
 
 
@@ -448,7 +451,7 @@ def main():
                    "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world} (shard.shard_bh of the global batch), no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get(args.config),
-                     "traffic_note": ("HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r2_run_m_pmc_*.txt), algorithmic %.4g" % ALGO_BYTES[args.config]) if args.config in PMC_TRAFFIC_BYTES else None,
+                     "traffic_note": ("HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r3_run_k_order_traffic.txt, r2_run_m_pmc_c5.txt), algorithmic %.4g" % ALGO_BYTES[args.config]) if args.config in PMC_TRAFFIC_BYTES else None,
                      "kernel": "sage_attn_kernel", "avg_launch_ms": round(kern_ms, 4),
                      "algorithmic_flops_per_launch": fl,
                      "peak_note": "harmonic blend of the dense MFMA peaks of the two halves: INT8 5.0 POPS (QK^T) and " + ("FP8 5.0 PF (MX-scaled instruction)" if cfg["pv"] == "fp8" else "FP16 2.5 PF") + " (PV)"},

@@ -1494,9 +1494,12 @@ static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
 
 // Causal dense grids: the order in which an XCD's workgroups take (head, query block) items (see the kernel's work-item mapping).
 // Returns the grid size.  Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first
-// order over contiguous runs.  Group size: the last group's work has to cover its own longest block on all resident slots,
-// G * nqblk * (nqblk + 1) / slots >= 2 * nqblk, or the launch ends on a tail of one head's long blocks; twice that measured best
-// (profiles/r3_run_j_work_order_ab.txt: N=8k prefers 2-4 heads -- eight spread the XCD's L2 over 16 MB of K/V --, N<=4k all eight).
+// order over contiguous runs.  Group size G (profiles/r3_run_j_work_order_ab.txt, r3_run_k_order_traffic.txt):
+//   balance: the last group's work has to cover its own longest block on all resident slots, G * nqblk * (nqblk + 1) / slots >=
+//            2 * nqblk, or the launch ends on a tail of one head's long blocks (C2, N=4k: G=2 988, G=4 1085 TFLOP/s);
+//   L2:      the G heads of a group stream their K/V at the same time; past the XCD's 4 MB L2 every further head is re-fetched
+//            (C3, 2 MB per head: FETCH_SIZE 105 k KiB at G=1, 148 k at G=2, 284 k at G=4, 587 k at G=8 for 7.4 / 8.9 / 9.3 % less
+//            time than head-major), so up to twice the balance size is taken only while the group fits the L2.
 // SAGE_ORDER_GROUP = 0 restores the head-major order, n > 0 forces the group size (experiments).
 static int g_work_order = -2;         // -2: not read yet
 int work_order()
@@ -1508,7 +1511,7 @@ int work_order()
     return g_work_order;
 }
 void set_work_order_mode(int group) { g_work_order = group; }
-static int set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
+static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8, bool masked)
 {
     q.order_group = 0;
     q.order_fold = 0;
@@ -1520,7 +1523,11 @@ static int set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
     const int hpx = nheads / 8, left = nheads % 8;
     const int wg_per_cu = head_dim == 64 ? 3 : 2;                 // SAGE_MIN_WAVES
     const int slots = 32 * wg_per_cu;
-    int grp = forced > 0 ? forced : (4 * slots + q.nqblk) / (q.nqblk + 1);
+    const int g_bal = (2 * slots + q.nqblk) / (q.nqblk + 1);
+    const long head_bytes = (long)q.Lk * head_dim * (pv_fp8 ? 2 : 3);              // INT8 K + FP8 / FP16 V image
+    const int g_l2 = (int)((4L << 20) / (head_bytes > 0 ? head_bytes : 1));
+    const int g_auto = g_bal > (2 * g_bal < g_l2 ? 2 * g_bal : g_l2) ? g_bal : (2 * g_bal < g_l2 ? 2 * g_bal : g_l2);
+    int grp = forced > 0 ? forced : g_auto;
     grp = grp > hpx ? hpx : grp;
     grp = grp < 1 ? 1 : grp;
     q.order_group = grp;
@@ -1535,7 +1542,7 @@ static int set_work_order(AttnParams &q, bool causal, int head_dim, bool masked)
 hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
 {
     AttnParams p = p_in;
-    const int nwork = set_work_order(p, causal, head_dim, false);
+    const int nwork = set_work_order(p, causal, head_dim, pv_fp8, false);
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
     if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, true, q_dtype == DT_F16 ? 1 : 2, stream);
@@ -1551,7 +1558,7 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
                        bool two_level, int mask_kind, hipStream_t stream)
 {
     AttnParams p = p_in;
-    const int nwork = set_work_order(p, causal, head_dim, mask_kind != 0);
+    const int nwork = set_work_order(p, causal, head_dim, pv_fp8, mask_kind != 0);
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
         if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)

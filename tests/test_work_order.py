@@ -7,10 +7,12 @@ short blocks on a CU.  The HIP code itself is pinned by tests/test_gpu_soak.py::
 import pytest
 
 
-def plan(nheads, nqblk, head_dim=128, forced=-1):
+def plan(nheads, nqblk, head_dim=128, forced=-1, pv_fp8=True):
     hpx, left = nheads // 8, nheads % 8
     wg = 3 if head_dim == 64 else 2
-    grp = forced if forced > 0 else (4 * 32 * wg + nqblk) // (nqblk + 1)
+    g_bal = (2 * 32 * wg + nqblk) // (nqblk + 1)
+    g_l2 = (4 << 20) // (nqblk * 128 * head_dim * (2 if pv_fp8 else 3))      # self-attention: Lk = 128 * nqblk
+    grp = forced if forced > 0 else max(g_bal, min(2 * g_bal, g_l2))
     grp = max(1, min(grp, hpx))
     cnt = left * ((nqblk + 7) // 8) + hpx * nqblk
     one_sorted_list = (left == 0 and grp >= hpx) or hpx == 0
@@ -66,6 +68,8 @@ def test_xcds_get_equal_weight_and_single_rounds_are_folded():
             if it is not None:
                 w[bid & 7] += 2 * (nqblk - it[1])         # 64-key tiles of the block (rank 0 = the longest)
         assert max(w) <= 1.02 * sum(w) / 8, (nheads, nqblk, w)
+    assert [plan(64, n)[0] for n in (8, 16, 32, 64, 128, 256)] == [8, 8, 4, 2, 1, 1]          # the N = 1k .. 32k sweep at B*H = 64
+    assert plan(64, 32, pv_fp8=False)[0] == 4 and plan(64, 64, head_dim=64)[0] == 4              # C2; D = 64 FP8 at N = 8k
     # one round: in-XCD indices i and i + 32 share a CU (tools/microbench/ubench7_dispatch.hip) -> long + short
     for nheads, nqblk in [(64, 8), (8, 48), (4, 128)]:
         grp, left, fold, nwg = plan(nheads, nqblk)
