@@ -67,6 +67,9 @@
 #ifndef SAGE_GRP4       // experiment: the FP8 pipelined loop's softmax in statements of four scores
 #define SAGE_GRP4 1
 #endif
+#ifndef SAGE_RSUM_MFMA   // experiment: FP16-PV CUDA form, pipelined loop: the row sum of the fp16-rounded P from the matrix pipe (a ones
+#define SAGE_RSUM_MFMA 0 // fragment against P, the reference's mma::rowsum_f16f16f32) instead of two v_fma_mix_f32 per score pair
+#endif
 #ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
 #define SAGE_ORDER_DEFAULT -1
 #endif
@@ -1070,6 +1073,7 @@ sage_attn_kernel(const AttnParams p)
             //    slot (t+2)%3 (K(t-1), read in iteration t-2, is dead) and V(t+1) into the V region of slot (t+1)%3 (V(t-2),
             //    read in iteration t-1, is dead); K(t+1) and V(t-1) were requested one and two iterations ago.
 #define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define A_RS0(acc, av, bv)  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
 #define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
@@ -1113,6 +1117,16 @@ sage_attn_kernel(const AttnParams p)
                 // CUDA kernel form (TWO_LEVEL false): row sum of the fp16-rounded P; Triton kernel form (TWO_LEVEL true): of the
                 // un-rounded P (see tile_iter)
                 constexpr bool RSUM16 = !TWO_LEVEL;
+                constexpr bool RSMFMA = RSUM16 && SAGE_RSUM_MFMA && D == 128;       // (D = 64: spills at three waves)
+                // RSMFMA: rsacc = ones(32 x 16) . P(t-1)^T chunk by chunk beside the PV MFMAs: every register of the lane holds the
+                // whole row sum of its query row (both lane halves); it joins l one tile late, l(t-1) = l + rs(t-1), then * alpha(t)
+                [[maybe_unused]] v16f rsacc;
+                [[maybe_unused]] v4i ones16 = {0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};
+                if constexpr (RSMFMA) {
+                    asm volatile("" : "+v"(ones16));
+#pragma unroll
+                    for (int i = 0; i < 16; i++) rsacc[i] = 0.0f;
+                }
                 auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
                     rescale();
                     const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
@@ -1182,7 +1196,14 @@ sage_attn_kernel(const AttnParams p)
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
-                        if constexpr (RSUM16) {
+                        if constexpr (RSMFMA) {
+                            asm volatile("v_add_f32 %0, 0xbe22f983, %3\n\tv_add_f32 %1, 0xbe22f983, %4\n\t"
+                                         "v_fma_f32 %0, %0, %5, -%7\n\tv_fma_f32 %1, %1, %6, -%7\n\t"
+                                         "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\t"
+                                         "s_nop 0\n\tv_cvt_pk_f16_f32 %2, %0, %1"
+                                         : "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                        } else if constexpr (RSUM16) {
                             // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
                             // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
                             // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
@@ -1213,7 +1234,12 @@ sage_attn_kernel(const AttnParams p)
                         for (int kk = 0; kk < C::KSTEPS; kk++)
                             kf[kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
                     };
-                    auto pv4 = [&](int dt, v4i (&vf)[4], int c) { A_PV16(o[dt], vf[c], pp[c]); };
+                    auto pv4 = [&](int dt, v4i (&vf)[4], int c) {
+                        A_PV16(o[dt], vf[c], pp[c]);
+                        if constexpr (RSMFMA) {                                  // the row-sum MFMA of chunk c rides behind channel tile 1 (D=64: 0)
+                            if (dt == (C::DT == 4 ? 1 : 0)) { if (c == 0) A_RS0(rsacc, ones16, pp[0]); else A_PV16(rsacc, ones16, pp[c]); }
+                        }
+                    };
                     auto qk_next = [&](int sb, int kk) {
                         if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
                         else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
@@ -1266,7 +1292,8 @@ sage_attn_kernel(const AttnParams p)
                     A_FENCE();
                     float ksc_next[NH][2];
                     load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
-                    l_run = l_run * alpha + (rs0 + rs1);
+                    if constexpr (RSMFMA) l_run = (l_run + (g == 0 ? rsacc[0] : 0.0f)) * alpha;     // lane-partial convention: half 0 carries the sum
+                    else l_run = l_run * alpha + (rs0 + rs1);
                     ksc[0][0] = ksc_next[0][0];
                     ksc[0][1] = ksc_next[0][1];
                     cur = nxt;
@@ -1317,11 +1344,18 @@ sage_attn_kernel(const AttnParams p)
                             A_PV16(o[dt], a, pA[c]);
                         }
                     }
+                    if constexpr (RSMFMA) {
+                        A_RS0(rsacc, ones16, pA[0]);
+#pragma unroll
+                        for (int c = 1; c < 4; c++) A_PV16(rsacc, ones16, pA[c]);
+                    }
                     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VP / 4) : "memory");
+                    if constexpr (RSMFMA) l_run += (g == 0 ? rsacc[0] : 0.0f);
                     __builtin_amdgcn_s_barrier();
                 }
             }
+#undef A_RS0
 #undef A_PV16
 #undef A_QK0
 #undef A_QK
