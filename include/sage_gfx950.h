@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 13
+#define SAGE_ABI_VERSION 14
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -85,6 +85,11 @@ SAGE_API void sage_set_attn64_mode(int mode);
  * and leaves the order to the hardware.  Process-wide; initialised from the environment variable SAGE_ORDER_GROUP. */
 SAGE_API int sage_work_order(void);
 SAGE_API void sage_set_work_order(int group);
+/* Host-side views of that order (csrc/sage_work_order.h, the code the kernels and launchers run; no GPU needed): the plan of a causal
+ * launch over nheads = B * Hq heads of nqblk 128-row query blocks -> grid size, *group / *fold / *left; and the (head, rank of the query
+ * block: 0 = the longest) that workgroup `bid` of a grid of `nwg` takes (returns 1, or 0 if that workgroup has no item, -1 on bad arguments). */
+SAGE_API int sage_debug_work_order_plan(int nheads, int nqblk, int64_t kv_len, int head_dim, int pv_fp8, int forced, int *group, int *fold, int *left);
+SAGE_API int sage_debug_work_item(int bid, int nwg, int nheads, int nqblk, int group, int fold, int left, int *head, int *qrank);
 
 /* Size in bytes of the tiled V^T image for `n_kv_tiles_total` 64-token tiles (all batches, heads). */
 SAGE_API int64_t sage_v_image_bytes(int head_dim, int fp8, int64_t n_kv_tiles_total);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 13
+ABI_VERSION = 14
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -30,6 +30,8 @@ SYMBOLS = {
     "sage_last_error": (ctypes.c_char_p, []),
     "sage_attn64_mode": (c_int, []),
     "sage_set_attn64_mode": (None, [_I]),
+    "sage_debug_work_order_plan": (c_int, [_I, _I, _L, _I, _I, _I, _P, _P, _P]),
+    "sage_debug_work_item": (c_int, [_I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sage_work_order": (c_int, []),
     "sage_set_work_order": (None, [_I]),
     "sage_v_image_bytes": (c_int64, [_I, _I, _L]),

@@ -28,6 +28,7 @@
 #include "sage_common.h"
 #include "sage_kernels.h"
 #include "sage_quant_math.h"
+#include "sage_work_order.h"
 #include <climits>
 #include <cstdlib>
 #include <type_traits>
@@ -172,40 +173,10 @@ sage_attn_kernel(const AttnParams p)
         // longest (causal) blocks of a head are dispatched first.  Measured alternatives (profiles/r1_run28_xcd_map.txt,
         // DESIGN.md 3.1): heads dealt to XCDs in rounds of 8 is 6-14 % slower where it spreads a head's K/V over all
         // eight L2s; shortest-first order -5 %, alternating long/short -21 %.
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-        const int nwg = gridDim.x;
-        const int qq = nwg >> 3, rr = nwg & 7;
-        int wid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-        if (CAUSAL && p.order_group > 0) {
-            // Causal work order (set_work_order below).  B * Hq = 8 * hq + R heads: every XCD owns hq whole heads; the R left-over
-            // heads are dealt to all eight XCDs by query block (octets of blocks, boustrophedon, so every XCD gets the same mix of
-            // long and short ones).  The XCD's list: the left-over heads' blocks first, then its own heads in groups of
-            // `order_group`; inside a group longest query block first ACROSS the heads, so the run ends on the shortest blocks of
-            // several heads instead of on one head's longest.  A grid that fits the XCD's resident slots in one round is folded, so
-            // that the two workgroups the dispatcher puts on one CU (in-XCD indices i and i + 32, tools/microbench/
-            // ubench7_dispatch.hip) are the i-th longest and the i-th shortest.
-            int r = idx;
-            if (p.order_fold != 0 && idx >= 32) r = qq - 1 - (idx - 32);
-            const int nleft = p.order_left, hpx = (p.B * p.Hq) >> 3;
-            const int left_cnt = nleft * ((nqblk + 7) >> 3);
-            int head, qrank;
-            if (r < left_cnt) {
-                const int oct = r / nleft;
-                head = r - oct * nleft;
-                qrank = 8 * oct + ((oct & 1) ? 7 - xcd : xcd);
-                if (qrank >= nqblk) return;
-            } else {
-                r -= left_cnt;
-                const int gsz = p.order_group * nqblk;
-                const int gi = r / gsz, within = r - gi * gsz;
-                const int gc = (hpx - gi * p.order_group) < p.order_group ? (hpx - gi * p.order_group) : p.order_group;
-                qrank = within / gc;
-                head = nleft + xcd * hpx + gi * p.order_group + (within - qrank * gc);
-            }
-            wid = head * nqblk + qrank;
-        }
-        const int bh = wid / nqblk;
-        qblk = nqblk - 1 - (wid - bh * nqblk);
+        int bh, qrank;
+        const WorkOrder wo = {CAUSAL ? p.order_group : 0, p.order_fold, p.order_left};      // causal work order: sage_work_order.h
+        if (!work_item(wo, blockIdx.x, gridDim.x, p.B * p.Hq, nqblk, bh, qrank)) return;
+        qblk = nqblk - 1 - qrank;
         b = bh / p.Hq;
         h = bh - b * p.Hq;
         hk = h / p.group;
@@ -1526,15 +1497,9 @@ static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
     return false;
 }
 
-// Causal dense grids: the order in which an XCD's workgroups take (head, query block) items (see the kernel's work-item mapping).
-// Returns the grid size.  Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first
-// order over contiguous runs.  Group size G (profiles/r3_run_j_work_order_ab.txt, r3_run_k_order_traffic.txt):
-//   balance: the last group's work has to cover its own longest block on all resident slots, G * nqblk * (nqblk + 1) / slots >=
-//            2 * nqblk, or the launch ends on a tail of one head's long blocks (C2, N=4k: G=2 988, G=4 1085 TFLOP/s);
-//   L2:      the G heads of a group stream their K/V at the same time; past the XCD's 4 MB L2 every further head is re-fetched
-//            (C3, 2 MB per head: FETCH_SIZE 105 k KiB at G=1, 148 k at G=2, 284 k at G=4, 587 k at G=8 for 7.4 / 8.9 / 9.3 % less
-//            time than head-major), so up to twice the balance size is taken only while the group fits the L2.
-// SAGE_ORDER_GROUP = 0 restores the head-major order, n > 0 forces the group size (experiments).
+// Causal dense grids: which (head, query block) item a workgroup takes -- sage_work_order.h (mapping, group-size rule, measurements).
+// Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first order over contiguous runs.
+// SAGE_ORDER_GROUP / sage_set_work_order: 0 restores the head-major order, n > 0 forces the group size (experiments).
 static int g_work_order = -2;         // -2: not read yet
 int work_order()
 {
@@ -1554,22 +1519,12 @@ static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8,
     if (q.cu_q != nullptr) return ((q.B * q.Hkv + 7) / 8) * 8 * q.group * q.nqblk;   // varlen: whole rounds of 8 (sequence, kv-head) units
     const int forced = work_order();
     if (!causal || masked || q.kv_split > 1 || q.nqblk <= 1 || forced == 0) return nheads * q.nqblk;
-    const int hpx = nheads / 8, left = nheads % 8;
-    const int wg_per_cu = head_dim == 64 ? 3 : 2;                 // SAGE_MIN_WAVES
-    const int slots = 32 * wg_per_cu;
-    const int g_bal = (2 * slots + q.nqblk) / (q.nqblk + 1);
-    const long head_bytes = (long)q.Lk * head_dim * (pv_fp8 ? 2 : 3);              // INT8 K + FP8 / FP16 V image
-    const int g_l2 = (int)((4L << 20) / (head_bytes > 0 ? head_bytes : 1));
-    const int g_auto = g_bal > (2 * g_bal < g_l2 ? 2 * g_bal : g_l2) ? g_bal : (2 * g_bal < g_l2 ? 2 * g_bal : g_l2);
-    int grp = forced > 0 ? forced : g_auto;
-    grp = grp > hpx ? hpx : grp;
-    grp = grp < 1 ? 1 : grp;
-    q.order_group = grp;
-    q.order_left = left;
-    const int cnt = left * ((q.nqblk + 7) / 8) + hpx * q.nqblk;
-    const bool one_sorted_list = (left == 0 && grp >= hpx) || hpx == 0;
-    q.order_fold = (wg_per_cu == 2 && cnt > 32 && cnt <= 64 && one_sorted_list) ? 1 : 0;
-    return 8 * cnt;
+    WorkOrder w;
+    const int grid = plan_work_order(w, nheads, q.nqblk, q.Lk, head_dim, pv_fp8, forced);
+    q.order_group = w.group;
+    q.order_fold = w.fold;
+    q.order_left = w.left;
+    return grid;
 }
 
 // per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue

@@ -3,6 +3,7 @@
 #include "../../include/sage_gfx950.h"
 #include "sage_common.h"
 #include "sage_kernels.h"
+#include "sage_work_order.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -111,6 +112,21 @@ SAGE_API int sage_abi_version(void) { return SAGE_ABI_VERSION; }
 SAGE_API const char *sage_last_error(void) { return g_err; }
 SAGE_API int sage_attn64_mode(void) { return sage::attn64_mode(); }
 SAGE_API void sage_set_attn64_mode(int mode) { sage::set_attn64_mode(mode < -1 ? -1 : (mode > 1 ? 1 : mode)); }
+// host-side views of sage_work_order.h (the code the kernels and launchers run), for tests without a GPU
+SAGE_API int sage_debug_work_order_plan(int nheads, int nqblk, int64_t kv_len, int head_dim, int pv_fp8, int forced, int *group, int *fold, int *left)
+{
+    if (nheads <= 0 || nqblk <= 0 || group == nullptr || fold == nullptr || left == nullptr) return fail(SAGE_EINVAL, "sage_debug_work_order_plan: bad argument");
+    sage::WorkOrder w;
+    const int grid = sage::plan_work_order(w, nheads, nqblk, (long)kv_len, head_dim, pv_fp8 != 0, forced);
+    *group = w.group; *fold = w.fold; *left = w.left;
+    return grid;
+}
+SAGE_API int sage_debug_work_item(int bid, int nwg, int nheads, int nqblk, int group, int fold, int left, int *head, int *qrank)
+{
+    if (head == nullptr || qrank == nullptr || nwg <= 0 || bid < 0 || bid >= nwg) return fail(SAGE_EINVAL, "sage_debug_work_item: bad argument");
+    const sage::WorkOrder w = {group, fold, left};
+    return sage::work_item(w, bid, nwg, nheads, nqblk, *head, *qrank) ? 1 : 0;
+}
 SAGE_API int sage_work_order(void) { return sage::work_order(); }
 SAGE_API void sage_set_work_order(int group) { sage::set_work_order_mode(group < -1 ? -1 : group); }
 
