@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 14
+#define SAGE_ABI_VERSION 15
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -303,6 +303,24 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                                       int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                       int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+
+/* The Triton-named API's attention (FP16 PV, tile product folded into the FP32 output, per-block k scales) with the PER-BLOCK Q
+ * quantisation in the kernel prologue: q (fp16 / bf16) is multiplied by q_premul (= sm_scale * log2 e), one scale per 128 query rows,
+ * Triton rounding -- bit-identical to sage_quant_qk_int8 (per_block, pre_scale = q_premul) + sage_attn_qk_int8_pv_f16(pv_accum =
+ * SAGE_PV_ACCUM_TRITON, sm_scale_log2 = 1), without the INT8 copy of Q and its scales in HBM.  lse nullable (log2 units).
+ * Replaces: quant_per_block.py:21-46 (the q half, core.py:284-286) + attn_qk_int8_per_block*.py forward. */
+SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
+                                           int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream);
+/* The packed / varlen form (sage_attn_qk_int8_pv_f16_varlen's operands without q_scale / cu_q_scale; q in fp16 / bf16).
+ * Replaces: quant_per_block_varlen.py:60-104 (the q half, core.py:436-439) + attn_qk_int8_block_varlen.py forward. */
+SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
+                                                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
+                                                  const int32_t *seq_order, int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                                  int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
+                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream);
 
 /* The same kernel over a key range split into kv_split chunks of Lk_chunk keys each (a whole number of 64-key tiles), folded
  * into the kv-head dimension: k / k_scale / v_image / v_scale / v_mean are the operands of the unsplit call viewed as

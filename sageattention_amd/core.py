@@ -124,6 +124,26 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     return o, lse
 
 
+@torch.compiler.disable
+def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_premul, return_lse):
+    """The Triton-named API's attention with the per-block Q quantisation in the kernel prologue
+    (``sage_attn_fused_qblock_pv_f16``): bit-identical to ``per_block_int8`` (q half) + the attention op."""
+    q = _aligned(q, 8)
+    B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q, tensor_layout)
+    _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
+    assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
+    o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
+    code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
+    rc = _cabi.load().sage_attn_fused_qblock_pv_f16(
+        _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
+        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+        int(is_causal), float(q_premul), code, code, _stream(q))
+    _cabi.check(rc, "sage_attn_fused_qblock_pv_f16")
+    return o, lse
+
+
 def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override: Optional[int]) -> int:
     """Number of key-range chunks S for a call whose grid would not fill the chip (0 = no split).  The reference kernels
     parallelise over (batch, head, 128-row q block) only, so few query rows against a long key range (cross-attention,
@@ -268,12 +288,17 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     if is_causal:
         assert q.size(1 if tensor_layout == "NHD" else 2) == k.size(1 if tensor_layout == "NHD" else 2), \
             "qo_len and kv_len must be equal for causal attention"
-    q_int8, q_scale, k_int8, k_scale = per_block_int8(q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
-                                                      quantization_backend=quantization_backend)
-    v_image = prep_v_fp16(v, tensor_layout)
     if is_causal:
         assert attn_mask is None, "Mask should be None for causal attention."        # core.py:310
-    if attn_mask is not None:
+    # the Q half of the per-block quantiser runs in the attention kernel's prologue (same bits, no INT8 copy of Q in HBM) unless the
+    # CUDA rounding convention or a mask is asked for
+    fuse_q = quantization_backend == "triton" and attn_mask is None and kwargs.get("fuse_q_quant", True)
+    q_int8, q_scale, k_int8, k_scale = per_block_int8(None if fuse_q else q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
+                                                      quantization_backend=quantization_backend)
+    v_image = prep_v_fp16(v, tensor_layout)
+    if fuse_q:
+        o, lse = _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, sm_scale * LOG2E, return_lse)
+    elif attn_mask is not None:
         o, lse = _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, dtype, tensor_layout, return_lse)
     else:
         o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,
@@ -296,8 +321,9 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     km = channel_mean_packed(k) if smooth_k else None   # mean over ALL packed tokens, as core.py:432-434
     if sm_scale is None:
         sm_scale = 1.0 / (head_dim_og ** 0.5)
+    fuse_q = kwargs.get("fuse_q_quant", True)      # the Q half of the quantiser in the attention kernel's prologue (same bits)
     q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
-        q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale)
+        None if fuse_q else q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale)
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
     v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k)
@@ -305,6 +331,14 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     code = _cabi.DTYPE_F16 if dtype == torch.float16 else _cabi.DTYPE_BF16
     # schedule the longest sequences first (device-side sort, no sync); results do not depend on the order
     order = torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
+    if fuse_q:
+        q = q if q.stride(-1) == 1 and q.stride(0) % 8 == 0 and q.stride(1) % 8 == 0 and q.data_ptr() % 16 == 0 else q.contiguous()
+        rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
+            _p(q), _p(k_int8), _p(v_image), _p(o), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_ks), _p(order),
+            cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q.stride(0), q.stride(1), k_int8.stride(0), k_int8.stride(1),
+            o.stride(0), o.stride(1), int(is_causal), float(sm_scale * LOG2E), code, code, _stream(o))
+        _cabi.check(rc, "sage_attn_fused_qblock_pv_f16_varlen")
+        return o[..., :head_dim_og]
     rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
         _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(q_scale), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_qs), _p(cu_ks),
         _p(order), cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),

@@ -132,7 +132,9 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 #endif
 }
 
-// QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue
+// QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue, per-thread groups;
+// 3 / 4 = fp16 / bf16 quantised in the prologue PER BLOCK of 128 rows after the multiplication by p.q_premul (quant_per_block.py:21-46
+// with sm_scale folded in: the Q half of the reference's Triton-named API and of sageattn_varlen),
 // ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
@@ -198,7 +200,7 @@ sage_attn_kernel(const AttnParams p)
         o_off = (long)q0 * p.o_sl + (long)h * p.o_sh;
         v_tile0 = (long)p.cu_ks[b] * p.Hkv + hk;
         v_tstride = p.Hkv;
-        qs_ptr = p.q_scale + ((long)p.cu_qs[b] + qblk) * p.Hq + h;    // [sum nblk, Hq]
+        qs_ptr = QF == 0 ? p.q_scale + ((long)p.cu_qs[b] + qblk) * p.Hq + h : nullptr;    // [sum nblk, Hq] (fused Q: no stored scales)
         qs_stride = 0;
         ks_ptr = p.k_scale + (long)p.cu_ks[b] * p.Hkv + hk;           // [sum nblk, Hkv]
         ks_tstride = p.Hkv;
@@ -410,7 +412,9 @@ sage_attn_kernel(const AttnParams p)
         // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
         // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
         // r, r+8, r+16, r+24 of the wave's 32-row tile, all 128 channels: lanes n = r (mod 8), both halves g.
-        constexpr int QDT = (QF == 1) ? DT_F16 : DT_BF16;
+        constexpr int QDT = (QF == 1 || QF == 3) ? DT_F16 : DT_BF16;
+        constexpr bool QBLOCK = QF >= 3;
+        const float premul = QBLOCK ? p.q_premul : 1.0f;
         const uint16_t *qrow = reinterpret_cast<const uint16_t *>(p.q) + q_off + (long)my_row * p.q_sl;
         const bool ok = my_row < Lq;
         float x[C::KSTEPS][16];
@@ -425,22 +429,37 @@ sage_attn_kernel(const AttnParams p)
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const unsigned w = raw[j >> 3][(j & 7) >> 1];
-                const float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                if constexpr (QBLOCK) f *= premul;          // x.to(float32) * sm_scale before the abs-max (quant_per_block.py:35-37)
                 x[ks][j] = f;
                 amax = fmaxf(amax, fabsf(f));
             }
         }
+        if constexpr (QBLOCK) {
+            // one scale for the workgroup's 128 rows: the wave's maximum, then the four waves' through 16 bytes of LDS (the K / V ring
+            // is receiving its first tiles meanwhile; only this word is waited for)
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            amax = fmaxf(amax, __shfl_xor(amax, 4));
+        }
         amax = fmaxf(amax, __shfl_xor(amax, 8));
         amax = fmaxf(amax, __shfl_xor(amax, 16));
         amax = fmaxf(amax, __shfl_xor(amax, 32));
-        const float sc = quant_scale(amax, QS_TRITON_THREAD);
+        if constexpr (QBLOCK) {
+            __shared__ float q_amax[4];
+            if (lane == 0) q_amax[wave] = amax;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            amax = fmaxf(fmaxf(q_amax[0], q_amax[1]), fmaxf(q_amax[2], q_amax[3]));
+        }
+        const float sc = quant_scale(amax, QBLOCK ? QS_TRITON : QS_TRITON_THREAD);
         const float y = quant_recip(sc);
         qsc = sc;
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ks++) {
             int q8[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) q8[j] = quant_round_triton_nz(x[ks][j], sc, y);
+            for (int j = 0; j < 16; j++) q8[j] = QBLOCK ? quant_round_triton(x[ks][j], sc, y) : quant_round_triton_nz(x[ks][j], sc, y);
 #pragma unroll
             for (int w = 0; w < 4; w++) qf[ks][w] = (int)pack_int8x4(q8[4 * w], q8[4 * w + 1], q8[4 * w + 2], q8[4 * w + 3]);
         }
@@ -1475,6 +1494,16 @@ static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t
     return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
 }
 
+// q in fp16 / bf16, quantised PER BLOCK in the prologue (QF 3 / 4): the Triton-named API's kernels (FP16 PV, per-block K scales,
+// tile product folded into the FP32 output), dense or varlen
+template <int D, bool CAUSAL, int QF>
+static hipError_t launch_fused_qblock_one(const AttnParams &p, int nwork, hipStream_t stream)
+{
+    constexpr int NH = D == 64 ? SAGE_NH_F8 : 1;
+    using C = TileCfg<D, false, NH>;
+    return launch_kernel(sage_attn_kernel<D, false, CAUSAL, false, true, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
+}
+
 // ---- route between the 128-row kernel family above and the 256-row one-wave-per-SIMD kernel (sage_attn64.hip) -------------
 static int g_attn64_mode = -2;       // -2: not read yet
 int attn64_mode()
@@ -1540,6 +1569,20 @@ hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal
     if (head_dim == 128) { if (pv_fp8) SAGE_FQ(128, true); else SAGE_FQ(128, false); }
     if (head_dim == 64) { if (pv_fp8) SAGE_FQ(64, true); else SAGE_FQ(64, false); }
 #undef SAGE_FQ
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_attn_fused_qblock(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, hipStream_t stream)
+{
+    AttnParams p = p_in;
+    const int nwork = set_work_order(p, causal, head_dim, false, false);
+    if (nwork <= 0) return hipSuccess;
+    if (q_dtype != DT_F16 && q_dtype != DT_BF16) return hipErrorInvalidValue;
+#define SAGE_FQB(D_) do { if (q_dtype == DT_F16) return causal ? launch_fused_qblock_one<D_, true, 3>(p, nwork, stream) : launch_fused_qblock_one<D_, false, 3>(p, nwork, stream); \
+                          return causal ? launch_fused_qblock_one<D_, true, 4>(p, nwork, stream) : launch_fused_qblock_one<D_, false, 4>(p, nwork, stream); } while (0)
+    if (head_dim == 128) SAGE_FQB(128);
+    if (head_dim == 64) SAGE_FQB(64);
+#undef SAGE_FQB
     return hipErrorInvalidValue;
 }
 

@@ -506,6 +506,69 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                           o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, false);
 }
 
+// q in fp16 / bf16, quantised per 128-row block in the kernel prologue (dense: cu_q == nullptr; varlen: packed tensors, B = nseq)
+static int fused_qblock_common(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
+                               const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_ks, const int32_t *seq_order,
+                               int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                               int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                               int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                               int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+{
+    const bool varlen = cu_q != nullptr;
+    SAGE_REQUIRE(q && k && v_image && o && k_scale, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
+    SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0 && (varlen || Lk > 0), "empty problem (B=%d Hq=%d Hkv=%d Lq=%d Lk=%d)", B, Hq, Hkv, Lq, Lk);
+    SAGE_REQUIRE(Hq % Hkv == 0, "num_qo_heads (%d) must be divisible by num_kv_heads (%d)", Hq, Hkv);
+    SAGE_REQUIRE(q_dtype == SAGE_DTYPE_F16 || q_dtype == SAGE_DTYPE_BF16, "bad q_dtype %d", q_dtype);
+    SAGE_REQUIRE(out_dtype == SAGE_DTYPE_F16 || out_dtype == SAGE_DTYPE_BF16, "bad out_dtype %d", out_dtype);
+    SAGE_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v_image) && aligned16(o), "q/k/v/o must be 16-byte aligned");
+    SAGE_REQUIRE(q_sl % 8 == 0 && q_sh % 8 == 0 && q_sb % 8 == 0, "q strides must be multiples of 8 elements");
+    SAGE_REQUIRE(k_sl % 16 == 0 && k_sh % 16 == 0 && k_sb % 16 == 0, "int8 k strides must be multiples of 16");
+    SAGE_REQUIRE(o_sl % 8 == 0 && o_sh % 8 == 0 && o_sb % 8 == 0, "output strides must be multiples of 8 elements");
+    SAGE_REQUIRE(!varlen || (cu_k && cu_ks), "varlen needs cu_seqlens_k and the k scale prefix array");
+    SAGE_REQUIRE(!varlen || lse == nullptr, "varlen returns no lse");
+    sage::AttnParams p{};
+    p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
+    p.k_scale = k_scale;
+    p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = nullptr; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+    p.Lq = Lq; p.Lk = Lk;
+    p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
+    p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+    p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+    p.o_sb = o_sb; p.o_sh = o_sh; p.o_sl = o_sl;
+    p.q_gran = sage::QG_PER_BLOCK; p.qs_per_blk = 1;
+    p.nqs = p.nqblk;
+    p.nks = (Lk + sage::BLKK - 1) / sage::BLKK;
+    p.out_dtype = out_dtype;
+    p.sm_scale_log2 = 1.0f;                 // sm_scale * log2(e) is folded into the quantised q (q_premul), as the reference's quantiser does
+    p.q_premul = q_premul;
+    return check_launch(sage::launch_attn_fused_qblock(p, D, is_causal != 0, q_dtype, static_cast<hipStream_t>(stream)),
+                        "sage_attn_fused_qblock launch");
+}
+
+SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
+                                           int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+{
+    return fused_qblock_common(q, k, v_image, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, B, Hq, Hkv, Lq, Lk, D,
+                               q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, q_dtype, out_dtype, stream);
+}
+
+SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
+                                                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
+                                                  const int32_t *seq_order, int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                                  int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
+                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+{
+    SAGE_REQUIRE(cu_seqlens_q != nullptr, "varlen needs cu_seqlens_q");
+    return fused_qblock_common(q, k, v_image, o, nullptr, k_scale, cu_seqlens_q, cu_seqlens_k, cu_k_scale, seq_order,
+                               nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
+                               is_causal, q_premul, q_dtype, out_dtype, stream);
+}
+
 SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
                                            const float *k_scale, const float *v_scale, const float *v_mean,
                                            int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,

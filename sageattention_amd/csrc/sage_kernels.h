@@ -39,6 +39,7 @@ struct AttnParams {
     int out_dtype;            // DT_F16 / DT_BF16
     long lse_sh;              // varlen lse head stride (unused for dense)
     float sm_scale_log2;      // multiplier taking dequantised scores to the log2 domain
+    float q_premul;           // fused per-block Q quantisation (launch_attn_fused_qblock): q is multiplied by this before its abs-max
     int order_group;          // set by the launchers (sage_attn.hip set_work_order): causal dense work order, heads per group; 0 = head-major
     int order_fold;           // 1: single-round grid, pair the i-th longest with the i-th shortest block on a CU
     int order_left;           // (B * Hq) % 8 heads whose query blocks are dealt to all eight XCDs
@@ -49,6 +50,9 @@ hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool caus
                        bool two_level, int mask_kind, hipStream_t stream);
 // q in fp16 / bf16, quantised per-thread in the kernel prologue; dense only.  FP8 PV: two-level accumulation; FP16 PV: FP32 accumulation
 hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream);
+// q in fp16 / bf16, quantised per 128-row block in the prologue after the multiplication by p.q_premul; FP16 PV in the Triton kernels'
+// form, per-block k scales; dense or varlen (p.cu_q)
+hipError_t launch_attn_fused_qblock(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream);
 
 // FP8 PV, dense, unmasked, D = 128 in the one-wave-per-SIMD form (sage_attn64.hip): 256 query rows per workgroup, 64 per wave.
 // qf: 0 = INT8 q + q_scale (any granularity), 1 / 2 = fp16 / bf16 q quantised in the prologue (per-thread groups)

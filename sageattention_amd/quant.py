@@ -98,12 +98,14 @@ def per_block_int8(q, k, km=None, BLKQ: int = 128, BLKK: int = 64, sm_scale: Opt
     into q.  Returns ``q_int8, q_scale[B,Hq,ceil(Lq/BLKQ)], k_int8, k_scale[B,Hkv,ceil(Lk/BLKK)]``.
     ``quantization_backend`` selects the reference's rounding convention: "triton"
     (quant_per_block.py:21-47) or "cuda" (quant.py:22-103 -> fused.cu:64-198)."""
-    D = q.size(-1)
+    D = k.size(-1)
     if sm_scale is None:
         sm_scale = D ** -0.5
     style = {"triton": _cabi.QSTYLE_TRITON, "cuda": _cabi.QSTYLE_CUDA}[quantization_backend]
     km = _squeeze_km(km, tensor_layout)
-    q_int8, q_scale = _quant(q, None, BLKQ, BLKQ, _cabi.GRAN_PER_BLOCK, False, style, sm_scale * LOG2E, tensor_layout, 1)
+    q_int8 = q_scale = None        # q=None: the K half only (the attention kernel quantises Q itself, sage_attn_fused_qblock_pv_f16)
+    if q is not None:
+        q_int8, q_scale = _quant(q, None, BLKQ, BLKQ, _cabi.GRAN_PER_BLOCK, False, style, sm_scale * LOG2E, tensor_layout, 1)
     k_int8, k_scale = _quant(k, km, BLKK, BLKK, _cabi.GRAN_PER_BLOCK, True, style, 1.0, tensor_layout, 1)
     return q_int8, q_scale, k_int8, k_scale
 
@@ -140,28 +142,35 @@ def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_se
     """Packed ``[sum L, H, D]`` per-block quantisation (quant_per_block_varlen.py:60-104).
     ``km`` (``[1, H, D]`` or ``[H, D]``) is subtracted from k inside the kernel, rounded to the
     input dtype exactly as the reference's ``k = k - km`` (core.py:432-434) does."""
-    q, k = _aligned(q, 8), _aligned(k, 8)
-    Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[-1]
+    k = _aligned(k, 8)
+    Hkv, D = k.shape[1], k.shape[-1]
     if sm_scale is None:
         sm_scale = D ** -0.5
-    nseq = cu_seqlens_q.shape[0] - 1
+    nseq = cu_seqlens_k.shape[0] - 1
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
     cu_qs, cu_ks = _cu_blocks(cu_q, BLKQ), _cu_blocks(cu_k, BLKK)
     # head-major storage behind the packed [sum L, H, D] view (see _quant)
-    q_int8 = torch.empty((Hq, q.shape[0], D), dtype=torch.int8, device=q.device).permute(1, 0, 2)
     k_int8 = torch.empty((Hkv, k.shape[0], D), dtype=torch.int8, device=k.device).permute(1, 0, 2)
-    # one host sync, as in the reference (`torch.empty((cu_seqlens_q_scale[-1], h_qo))`, :75)
-    nq, nk = int(cu_qs[-1].item()), int(cu_ks[-1].item())
-    q_scale = torch.empty((nq, Hq), dtype=torch.float32, device=q.device)
+    lib = _cabi.load()
+    q_int8 = q_scale = None        # q=None: the K half only (sage_attn_fused_qblock_pv_f16_varlen quantises Q in the attention kernel)
+    if q is not None:
+        q = _aligned(q, 8)
+        Hq = q.shape[1]
+        q_int8 = torch.empty((Hq, q.shape[0], D), dtype=torch.int8, device=q.device).permute(1, 0, 2)
+        # one host sync, as in the reference (`torch.empty((cu_seqlens_q_scale[-1], h_qo))`, :75)
+        nq = int(cu_qs[-1].item())
+        q_scale = torch.empty((nq, Hq), dtype=torch.float32, device=q.device)
+        rc = lib.sage_quant_qk_int8_varlen(_p(q), None, _p(q_int8), _p(q_scale), _p(cu_q), _p(cu_qs), nseq, int(max_seqlen_q),
+                                           Hq, D, q.stride(0), q.stride(1), q_int8.stride(0), q_int8.stride(1), 0,
+                                           BLKQ, float(sm_scale * LOG2E), _dtype_code(q), _stream(q))
+        _cabi.check(rc, "sage_quant_qk_int8_varlen(q)")
+    # the public quantiser returns the reference's shapes (`cu_seqlens_k_scale[-1]`, one host sync, quant_per_block_varlen.py:75-76); the
+    # K-only form used by sageattn_varlen allocates the bound sum ceil(L_i / BLKK) <= ceil(sum L / BLKK) + nseq instead and never syncs
+    nk = int(cu_ks[-1].item()) if q is not None else (k.shape[0] + BLKK - 1) // BLKK + nseq
     k_scale = torch.empty((nk, Hkv), dtype=torch.float32, device=k.device)
     if km is not None:
         km = km.reshape(Hkv, D).contiguous()
-    lib = _cabi.load()
-    rc = lib.sage_quant_qk_int8_varlen(_p(q), None, _p(q_int8), _p(q_scale), _p(cu_q), _p(cu_qs), nseq, int(max_seqlen_q),
-                                       Hq, D, q.stride(0), q.stride(1), q_int8.stride(0), q_int8.stride(1), 0,
-                                       BLKQ, float(sm_scale * LOG2E), _dtype_code(q), _stream(q))
-    _cabi.check(rc, "sage_quant_qk_int8_varlen(q)")
     rc = lib.sage_quant_qk_int8_varlen(_p(k), _p(km), _p(k_int8), _p(k_scale), _p(cu_k), _p(cu_ks), nseq, int(max_seqlen_k),
                                        Hkv, D, k.stride(0), k.stride(1), k_int8.stride(0), k_int8.stride(1), D,
                                        BLKK, 1.0, _dtype_code(k), _stream(k))

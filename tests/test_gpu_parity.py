@@ -1018,6 +1018,66 @@ def test_fused_q_quant_is_bit_identical_to_the_separate_quantiser(shape, dt, lay
         assert torch.equal(o2, o0)
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 2, 300, 300, 128), (1, 3, 3, 129, 1000, 64), (1, 8, 8, 1024, 1024, 128), (2, 2, 1, 5, 70, 128),
+                                   (1, 2, 2, 640, 640, 64)], ids=["gqa300", "cross_d64", "n1024", "tiny", "d64_640"])
+@pytest.mark.parametrize("dt,layout,causal", [(0, "HND", False), (1, "NHD", True), (1, "HND", True)])
+def test_fused_per_block_q_quant_is_bit_identical_to_the_separate_quantiser(shape, dt, layout, causal):
+    """sage_attn_fused_qblock_pv_f16 (the default route of the Triton-named API) quantises Q per 128-row block in the kernel prologue with
+    the arithmetic of the stand-alone per-block quantiser (sm_scale * log2 e folded in first): outputs and LSE equal the two-kernel
+    route bit for bit, so the reference-fixture parity of that route carries over."""
+    B, Hq, Hkv, Lq, Lk, D = shape
+    if causal and Lq != Lk:
+        pytest.skip("the Triton-named API's causal mask is for self-attention")
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=78, kbias=1.0)
+    qd, kd, vd = to_dev(q, layout), to_dev(k, layout), to_dev(v, layout)
+    o1, l1 = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True)
+    o0, l0 = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True, fuse_q_quant=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1.float()).all()
+    assert torch.equal(o1, o0) and torch.equal(l1, l0)
+    o3 = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, tensor_layout=layout, is_causal=causal, smooth_k=False, sm_scale=0.2)
+    o4 = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, tensor_layout=layout, is_causal=causal, smooth_k=False, sm_scale=0.2, fuse_q_quant=False)
+    assert torch.equal(o3, o4)
+    # an all-zero query block (scale 0: every q_int8 is 0, as the stand-alone quantiser gives) and a strided q view
+    qz = qd.clone()
+    if layout == "HND":
+        qz[:, :, :128] = 0
+    else:
+        qz[:, :128] = 0
+    assert torch.equal(sa.sageattn_qk_int8_pv_fp16_triton(qz, kd, vd, tensor_layout=layout, is_causal=causal),
+                       sa.sageattn_qk_int8_pv_fp16_triton(qz, kd, vd, tensor_layout=layout, is_causal=causal, fuse_q_quant=False))
+    if layout == "NHD":
+        qkv = torch.stack([qd, qd, qd], dim=2)                       # [B, L, 3, H, D]
+        assert torch.equal(sa.sageattn_qk_int8_pv_fp16_triton(qkv[:, :, 1], kd, vd, tensor_layout=layout, is_causal=causal), o0)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dt,D,hq,hkv", [(1, 128, 8, 2), (0, 64, 4, 4)])
+def test_varlen_fused_per_block_q_quant_is_bit_identical(causal, dt, D, hq, hkv):
+    """sageattn_varlen's default route (sage_attn_fused_qblock_pv_f16_varlen: Q quantised per block in the attention kernel, no host sync)
+    against the reference-shaped two-kernel route (per_block_int8_varlen's Q half + sage_attn_qk_int8_pv_f16_varlen): same bits."""
+    lens = [1, 127, 128, 129, 700, 64, 1000]
+    total = sum(lens)
+    g = torch.Generator().manual_seed(123)
+    T = torch.float16 if dt == 0 else torch.bfloat16
+    q = torch.randn(total, hq, D, generator=g).to(T).to(DEV)
+    k = (torch.randn(total, hkv, D, generator=g) + torch.randn(1, hkv, D, generator=g)).to(T).to(DEV)
+    v = torch.randn(total, hkv, D, generator=g).to(T).to(DEV)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    o1 = sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal)
+    o0 = sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal, fuse_q_quant=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1.float()).all() and torch.equal(o1, o0)
+    if not causal:                     # cross attention: other key lengths, a strided q (slice of a fused QKV projection)
+        klens = [5, 64, 200, 77, 1000, 640, 3]
+        cuk = torch.tensor([0] + list(np.cumsum(klens)), dtype=torch.int32, device=DEV)
+        k2, v2 = k[:sum(klens)].contiguous(), v[:sum(klens)].contiguous()
+        qkv = torch.stack([q, q], dim=1)                              # [T, 2, H, D]
+        o3 = sa.sageattn_varlen(qkv[:, 1], k2, v2, cu, cuk, max(lens), max(klens))
+        o2 = sa.sageattn_varlen(q, k2, v2, cu, cuk, max(lens), max(klens), fuse_q_quant=False)
+        assert torch.equal(o3, o2)
+
+
 def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():
     import time
     from sageattention_amd.graph import GraphedSageAttn
