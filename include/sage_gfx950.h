@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 15
+#define SAGE_ABI_VERSION 16
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -114,6 +114,14 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
                        int64_t mean_sb, int64_t mean_sh,
                        int blk, int warp, int gran, int is_key, int style,
                        float pre_scale, int dtype, void *stream);
+
+/* The index arrays of a packed-batch call in one launch: cu_q_scale / cu_k_scale = exclusive prefix sums of ceil(L_i / blkq) and
+ * ceil(L_i / blkk) (nseq + 1 entries each; cu_q_scale nullable), seq_order = the sequences by descending query length (the attention
+ * launcher's processing order; results do not depend on it).  nseq <= sage_varlen_plan_max_seqs().
+ * Replaces: the torch prefix sums of quant_per_block_varlen.py:68-73. */
+SAGE_API int sage_varlen_plan_max_seqs(void);
+SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
+                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order, void *stream);
 
 /*
  * Same for packed variable-length batches x[sum L, H, D] (per-block only).

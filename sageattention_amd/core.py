@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import _cabi, ops
 from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
-                    per_channel_fp8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean)
+                    per_channel_fp8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean, varlen_plan)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
 _FUSE_Q16_DEFAULT = __import__("os").environ.get("SAGE_FUSE_Q16", "1") != "0"      # debugging switch
@@ -322,15 +322,20 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     if sm_scale is None:
         sm_scale = 1.0 / (head_dim_og ** 0.5)
     fuse_q = kwargs.get("fuse_q_quant", True)      # the Q half of the quantiser in the attention kernel's prologue (same bits)
-    q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
-        None if fuse_q else q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale)
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
-    v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k)
+    # fused route: block-count prefix sums and the longest-first processing order from one small launch, no host synchronisation (the
+    # reference sizes its scale tensors with .item(); here they are allocated at a bound known on the host)
+    plan = varlen_plan(cu_q, cu_k) if fuse_q else None
+    q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
+        None if fuse_q else q, k, cu_q, cu_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale,
+        cu_ks=plan[1] if plan is not None else None)
+    nseq = cu_q.shape[0] - 1
+    v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k, ntiles=((k.shape[0] + 63) // 64 + nseq) if fuse_q else None)
     o = torch.empty(q.shape, dtype=dtype, device=q.device)
     code = _cabi.DTYPE_F16 if dtype == torch.float16 else _cabi.DTYPE_BF16
-    # schedule the longest sequences first (device-side sort, no sync); results do not depend on the order
-    order = torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
+    # schedule the longest sequences first (on the device, no sync); results do not depend on the order
+    order = plan[2] if plan is not None else torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
     if fuse_q:
         q = q if q.stride(-1) == 1 and q.stride(0) % 8 == 0 and q.stride(1) % 8 == 0 and q.data_ptr() % 16 == 0 else q.contiguous()
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(

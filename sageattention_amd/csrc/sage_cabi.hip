@@ -197,6 +197,17 @@ SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *
     return check_launch(sage::launch_quant_int8(p, static_cast<hipStream_t>(stream)), "sage_quant_qk_int8_varlen launch");
 }
 
+SAGE_API int sage_varlen_plan_max_seqs(void) { return sage::kVarlenPlanMaxSeq; }
+SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
+                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order, void *stream)
+{
+    SAGE_REQUIRE(cu_seqlens_q && cu_seqlens_k && cu_k_scale && seq_order, "null tensor pointer");
+    SAGE_REQUIRE(nseq > 0 && nseq <= sage::kVarlenPlanMaxSeq, "nseq must be in 1 .. %d (got %d)", sage::kVarlenPlanMaxSeq, nseq);
+    SAGE_REQUIRE(blkq > 0 && blkk > 0, "block sizes must be positive");
+    return check_launch(sage::launch_varlen_plan(cu_seqlens_q, cu_seqlens_k, nseq, blkq, blkk, cu_q_scale, cu_k_scale, seq_order,
+                                                 static_cast<hipStream_t>(stream)), "sage_varlen_plan launch");
+}
+
 static int stats_common(const void *x, void *mean_out, float *ws, float *stats, int B, int H, int L, int D,
                         int64_t x_sb, int64_t x_sh, int64_t x_sl, int dtype, void *stream, const char *what)
 {

@@ -87,6 +87,10 @@ struct QuantParams {
     float pre_scale;
 };
 hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream);
+// packed batches: prefix sums of the per-sequence block counts and the longest-first processing order, one launch (nseq <= kVarlenPlanMaxSeq)
+constexpr int kVarlenPlanMaxSeq = 1024;
+hipError_t launch_varlen_plan(const int32_t *cu_q, const int32_t *cu_k, int nseq, int blkq, int blkk,
+                              int32_t *cu_qs, int32_t *cu_ks, int32_t *order, hipStream_t stream);
 
 // ---- per-channel statistics over the sequence (K mean, V amax / mean) -----------------------------
 #ifndef SAGE_STATS_SLAB

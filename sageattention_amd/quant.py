@@ -137,8 +137,25 @@ def _cu_blocks(cu: torch.Tensor, blk: int) -> torch.Tensor:
 
 
 @_eager
+def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: int = 128, BLKK: int = 64, want_q_blocks: bool = False):
+    """The index arrays of a packed-batch call in one launch (``sage_varlen_plan``): ``(cu_qs | None, cu_ks, order)`` -- prefix sums of
+    the per-sequence block counts (the reference's torch ops, quant_per_block_varlen.py:68-73) and the sequences by descending query
+    length.  ``cu_seqlens_*`` int32, contiguous; at most ``sage_varlen_plan_max_seqs()`` sequences (``None`` otherwise)."""
+    nseq = cu_seqlens_q.shape[0] - 1
+    lib = _cabi.load()
+    if nseq < 1 or nseq > lib.sage_varlen_plan_max_seqs() or cu_seqlens_q.dtype != torch.int32 or cu_seqlens_k.dtype != torch.int32:
+        return None
+    dev = cu_seqlens_q.device
+    cu_qs = torch.empty((nseq + 1,), dtype=torch.int32, device=dev) if want_q_blocks else None
+    cu_ks = torch.empty((nseq + 1,), dtype=torch.int32, device=dev)
+    order = torch.empty((nseq,), dtype=torch.int32, device=dev)
+    rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, BLKQ, BLKK, _p(cu_qs), _p(cu_ks), _p(order), _stream(cu_seqlens_q))
+    _cabi.check(rc, "sage_varlen_plan")
+    return cu_qs, cu_ks, order
+
+
 def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=None,
-                          BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None):
+                          BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None, cu_ks: Optional[torch.Tensor] = None):
     """Packed ``[sum L, H, D]`` per-block quantisation (quant_per_block_varlen.py:60-104).
     ``km`` (``[1, H, D]`` or ``[H, D]``) is subtracted from k inside the kernel, rounded to the
     input dtype exactly as the reference's ``k = k - km`` (core.py:432-434) does."""
@@ -149,7 +166,9 @@ def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_se
     nseq = cu_seqlens_k.shape[0] - 1
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
-    cu_qs, cu_ks = _cu_blocks(cu_q, BLKQ), _cu_blocks(cu_k, BLKK)
+    cu_qs = _cu_blocks(cu_q, BLKQ) if q is not None else None
+    if cu_ks is None:              # (sageattn_varlen passes the array of varlen_plan)
+        cu_ks = _cu_blocks(cu_k, BLKK)
     # head-major storage behind the packed [sum L, H, D] view (see _quant)
     k_int8 = torch.empty((Hkv, k.shape[0], D), dtype=torch.int8, device=k.device).permute(1, 0, 2)
     lib = _cabi.load()
@@ -333,11 +352,14 @@ def sub_mean(v: torch.Tensor, tensor_layout: str = "HND"):
 
 
 @_eager
-def prep_v_fp16_varlen(v: torch.Tensor, cu_seqlens_k: torch.Tensor, cu_tiles: torch.Tensor, max_seqlen_k: int) -> torch.Tensor:
-    """Packed ``[sum L, H, D]`` V -> tile image ``[cu_tiles[-1], H, D, 64]`` fp16."""
+def prep_v_fp16_varlen(v: torch.Tensor, cu_seqlens_k: torch.Tensor, cu_tiles: torch.Tensor, max_seqlen_k: int,
+                       ntiles: Optional[int] = None) -> torch.Tensor:
+    """Packed ``[sum L, H, D]`` V -> tile image ``[cu_tiles[-1], H, D, 64]`` fp16.  ``ntiles``: an upper bound of ``cu_tiles[-1]``
+    known on the host (``ceil(sum L / 64) + nseq``) instead of the host synchronisation on the exact count."""
     v = _aligned(v, 8)
     H, D = v.shape[1], v.shape[2]
-    ntiles = int(cu_tiles[-1].item())
+    if ntiles is None:
+        ntiles = int(cu_tiles[-1].item())
     v_image = torch.empty((ntiles, H, D, 64), dtype=torch.float16, device=v.device)
     rc = _cabi.load().sage_prep_v_f16_varlen(_p(v), _p(v_image), _p(cu_seqlens_k), _p(cu_tiles), cu_seqlens_k.shape[0] - 1,
                                              int(max_seqlen_k), H, D, v.stride(0), v.stride(1), _dtype_code(v), _stream(v))

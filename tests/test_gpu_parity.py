@@ -1078,6 +1078,23 @@ def test_varlen_fused_per_block_q_quant_is_bit_identical(causal, dt, D, hq, hkv)
         assert torch.equal(o3, o2)
 
 
+def test_varlen_plan_matches_the_torch_prefix_sums():
+    """sage_varlen_plan (one launch) against the reference's torch ops (quant_per_block_varlen.py:68-73) and a sort by length."""
+    g = torch.Generator().manual_seed(5)
+    for nseq in (1, 2, 7, 64, 333, 1024):
+        lq = torch.randint(0, 5000, (nseq,), generator=g)
+        lk = torch.randint(0, 5000, (nseq,), generator=g)
+        lq[0] = lq[-1]                                                 # a tie
+        cu_q = torch.nn.functional.pad(lq.cumsum(0), (1, 0)).to(torch.int32).to(DEV)
+        cu_k = torch.nn.functional.pad(lk.cumsum(0), (1, 0)).to(torch.int32).to(DEV)
+        cu_qs, cu_ks, order = sq.varlen_plan(cu_q, cu_k, want_q_blocks=True)
+        assert torch.equal(cu_qs.cpu(), torch.nn.functional.pad(((lq + 127) // 128).cumsum(0), (1, 0)).to(torch.int32))
+        assert torch.equal(cu_ks.cpu(), torch.nn.functional.pad(((lk + 63) // 64).cumsum(0), (1, 0)).to(torch.int32))
+        o = order.cpu().long()
+        assert sorted(o.tolist()) == list(range(nseq)) and (lq[o][:-1] >= lq[o][1:]).all()
+    assert sq.varlen_plan(torch.zeros(1026, dtype=torch.int32, device=DEV), torch.zeros(1026, dtype=torch.int32, device=DEV)) is None
+
+
 def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():
     import time
     from sageattention_amd.graph import GraphedSageAttn
