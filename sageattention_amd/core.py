@@ -337,7 +337,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     # schedule the longest sequences first (on the device, no sync); results do not depend on the order
     order = plan[2] if plan is not None else torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
     if fuse_q:
-        q = q if q.stride(-1) == 1 and q.stride(0) % 8 == 0 and q.stride(1) % 8 == 0 and q.data_ptr() % 16 == 0 else q.contiguous()
+        q = _aligned(q, 8)
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_ks), _p(order),
             cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q.stride(0), q.stride(1), k_int8.stride(0), k_int8.stride(1),
