@@ -282,7 +282,17 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     torch.cuda.set_device(v.device)
     q, k, v, head_dim_og = _pad_head_dim(q, k, v)
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
-    km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
+    # K mean + INT8 K (Triton rounding) + the fp16 V image as ONE launch that reads K and V once (sage_prepass_kv), when it is the faster route
+    k_done = v_image = None
+    if quantization_backend == "triton" and k.shape == v.shape and _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")):
+        km_s, k8, ks, v_image, _, _ = prepass_kv_fp8(k, v, tensor_layout, smooth_k=smooth_k, qk_quant_gran="per_block_triton", v_fp16=True)
+        k_done = (k8, ks)
+        km, lse_correction = None, None
+        if smooth_k:
+            km = km_s.unsqueeze(1 if tensor_layout == "NHD" else 2)
+            lse_correction = _lse_correction(q, km, tensor_layout) if return_lse else None
+    else:
+        km, lse_correction = _smooth_k(q, k, tensor_layout, smooth_k, return_lse)
     if sm_scale is None:
         sm_scale = 1.0 / (head_dim_og ** 0.5)
     if is_causal:
@@ -294,8 +304,9 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     # CUDA rounding convention or a mask is asked for
     fuse_q = quantization_backend == "triton" and attn_mask is None and kwargs.get("fuse_q_quant", True)
     q_int8, q_scale, k_int8, k_scale = per_block_int8(None if fuse_q else q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
-                                                      quantization_backend=quantization_backend)
-    v_image = prep_v_fp16(v, tensor_layout)
+                                                      quantization_backend=quantization_backend, k_done=k_done)
+    if v_image is None:
+        v_image = prep_v_fp16(v, tensor_layout)
     if fuse_q:
         o, lse = _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, sm_scale * LOG2E, return_lse)
     elif attn_mask is not None:

@@ -364,7 +364,9 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
         SAGE_REQUIRE(((lpad - 1) * k_sl + D) * 2 < (int64_t)1 << 32 && (lpad - 1) * ko_sl + D < (int64_t)1 << 32,
                      "one head of k (rounded up to whole 512-row slabs) spans 4 GiB or more: the kernel addresses a head with 32-bit buffer offsets");
         SAGE_REQUIRE(k_blk == 64 || k_blk == 128, "k_blk must be 64 or 128 (got %d)", k_blk);
-        SAGE_REQUIRE(k_style == sage::QS_CUDA || k_style == sage::QS_TRITON_THREAD, "k_style must be the CUDA (1) or the per-thread Triton (2) convention (got %d)", k_style);
+        SAGE_REQUIRE(k_style == sage::QS_CUDA || k_style == sage::QS_TRITON_THREAD || k_style == sage::QS_TRITON,
+                     "k_style must be the Triton per-block (0), the CUDA (1) or the per-thread Triton (2) convention (got %d)", k_style);
+        SAGE_REQUIRE(k_style != sage::QS_TRITON || qk_quant_gran == SAGE_GRAN_PER_BLOCK, "the Triton per-block convention goes with per-block scales");
         if (qk_quant_gran == SAGE_GRAN_PER_BLOCK) p.k_gran = sage::GR_BLOCK;
         else if (qk_quant_gran == SAGE_GRAN_PER_THREAD) p.k_gran = sage::GR_THREAD_K;
         else return fail(SAGE_EINVAL, "bad k granularity %d (per-block or per-thread)", qk_quant_gran);

@@ -333,7 +333,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         const unsigned ooff = (unsigned)((row0 + r0) * (int)p.ko_sl + c4), ostep = (unsigned)(RPI * (int)p.ko_sl);
 
         // STYLE: 0 the CUDA quantiser (fp32 difference, round-to-nearest-even, fused.cu:131-172), 1 Triton rounding with
-        // the epsilon scale (quant_per_thread.py:41-44) -- the two K conventions of the reference's CUDA entry points
+        // the epsilon scale (quant_per_thread.py:41-44) -- the two K conventions of the reference's CUDA entry points --,
+        // 2 Triton rounding with the plain scale amax / 127, zero for an all-zero group (quant_per_block.py:41-44: the Triton-named API)
         auto quantise = [&](auto style_tag, auto smooth_tag) {
             constexpr int STYLE = decltype(style_tag)::value;
             constexpr bool SMOOTH = decltype(smooth_tag)::value;
@@ -426,7 +427,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if constexpr (STYLE == 0) q[j] = quant_round_cuda(f[j], y);
-                        else q[j] = quant_round_triton_nz(f[j], sc, y);
+                        else if constexpr (STYLE == 1) q[j] = quant_round_triton_nz(f[j], sc, y);
+                        else q[j] = quant_round_triton(f[j], sc, y);
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(pack_int8x4(q[0], q[1], q[2], q[3]), orsrc, orun, 0, SAGE_PP_NT ? 2 : 0);
                     orun += ostep;
@@ -439,7 +441,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             if (smooth) quantise(style_tag, std::true_type{}); else quantise(style_tag, std::false_type{});
         };
         if (p.k_style == QS_CUDA) by_smooth(std::integral_constant<int, 0>{});
-        else by_smooth(std::integral_constant<int, 1>{});          // QS_TRITON_THREAD (checked by the C ABI)
+        else if (p.k_style == QS_TRITON_THREAD) by_smooth(std::integral_constant<int, 1>{});
+        else by_smooth(std::integral_constant<int, 2>{});          // QS_TRITON (the C ABI admits these three)
     } else {
         // ---- 3b. V: tile image, two 64-token tiles per LDS stage (the arithmetic of prep_v_kernel) ------------------------
         const bool smooth = p.v_mean != nullptr;

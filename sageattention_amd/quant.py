@@ -93,7 +93,7 @@ def _quant(x, km, blk, warp, gran, is_key, style, pre_scale, tensor_layout, nslo
 
 
 def per_block_int8(q, k, km=None, BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None,
-                   tensor_layout: str = "HND", quantization_backend: str = "triton"):
+                   tensor_layout: str = "HND", quantization_backend: str = "triton", k_done=None):
     """Per-block INT8 quantisation of q (128 rows) and k (64 rows); ``sm_scale*log2e`` is folded
     into q.  Returns ``q_int8, q_scale[B,Hq,ceil(Lq/BLKQ)], k_int8, k_scale[B,Hkv,ceil(Lk/BLKK)]``.
     ``quantization_backend`` selects the reference's rounding convention: "triton"
@@ -106,7 +106,10 @@ def per_block_int8(q, k, km=None, BLKQ: int = 128, BLKK: int = 64, sm_scale: Opt
     q_int8 = q_scale = None        # q=None: the K half only (the attention kernel quantises Q itself, sage_attn_fused_qblock_pv_f16)
     if q is not None:
         q_int8, q_scale = _quant(q, None, BLKQ, BLKQ, _cabi.GRAN_PER_BLOCK, False, style, sm_scale * LOG2E, tensor_layout, 1)
-    k_int8, k_scale = _quant(k, km, BLKK, BLKK, _cabi.GRAN_PER_BLOCK, True, style, 1.0, tensor_layout, 1)
+    if k_done is not None:          # (k_int8, k_scale) already produced by the one-launch pre-pass (core.sageattn_qk_int8_pv_fp16_triton)
+        k_int8, k_scale = k_done
+    else:
+        k_int8, k_scale = _quant(k, km, BLKK, BLKK, _cabi.GRAN_PER_BLOCK, True, style, 1.0, tensor_layout, 1)
     return q_int8, q_scale, k_int8, k_scale
 
 
@@ -283,7 +286,8 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     Returns ``(km [B,H,D] | None, k_int8, k_scale, v_image, v_scale, vm)``; ``v=None`` runs the K half only
     (``v_image, v_scale, vm`` are None).  ``qk_quant_gran`` "per_thread" gives 4 k scales per BLKK keys with the
     Triton-per-thread rounding, "per_warp" / "per_block" one scale per BLKK keys with the CUDA rounding
-    (quant.py:105-180) -- the K conventions of the reference's CUDA entry points.  ``v_fp16=True`` (FP16-PV entry points) makes
+    (quant.py:105-180) -- the K conventions of the reference's CUDA entry points --, "per_block_triton" one scale per BLKK keys with
+    the Triton rounding (quant_per_block.py:21-46, the Triton-named API).  ``v_fp16=True`` (FP16-PV entry points) makes
     the V half the fp16 tile image of ``prep_v_fp16`` instead (``v_scale`` and ``vm`` are then None).  ``sync``: optional
     caller-owned int32 scratch of ``sage_prepass_sync_words(B, H)`` words (to inspect with ``prepass_failed_heads`` afterwards)."""
     k = _aligned(k, 8)
@@ -295,6 +299,8 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     _, _, _, _, ob, oh, ol = _dims(k_int8, tensor_layout)
     if qk_quant_gran == "per_thread":
         gran, style, slots = _cabi.GRAN_PER_THREAD, _cabi.QSTYLE_TRITON_THREAD, 4
+    elif qk_quant_gran == "per_block_triton":      # the Triton-named API's K half: per-block scales, Triton rounding (quant_per_block.py:21-46)
+        gran, style, slots = _cabi.GRAN_PER_BLOCK, _cabi.QSTYLE_TRITON, 1
     else:
         gran, style, slots = _cabi.GRAN_PER_BLOCK, _cabi.QSTYLE_CUDA, 1
     k_scale = torch.empty((B, H, ((L + BLKK - 1) // BLKK) * slots), dtype=torch.float32, device=dev)

@@ -23,6 +23,8 @@ def _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran):
     km = quant.channel_mean(k, layout) if smooth_k else None
     if gran == "per_thread":
         k8, ks = quant._quant(k, km, blkk, blkk, _cabi.GRAN_PER_THREAD, True, _cabi.QSTYLE_TRITON_THREAD, 1.0, layout, 4)
+    elif gran == "per_block_triton":
+        k8, ks = quant._quant(k, km, blkk, blkk, _cabi.GRAN_PER_BLOCK, True, _cabi.QSTYLE_TRITON, 1.0, layout, 1)
     else:
         k8, ks = quant._quant(k, km, blkk, blkk, _cabi.GRAN_PER_BLOCK, True, _cabi.QSTYLE_CUDA, 1.0, layout, 1)
     vi, vs, vm = quant.per_channel_fp8(v, tensor_layout=layout, scale_max=448.0, smooth_v=smooth_v)
@@ -55,6 +57,10 @@ CASES = [  # B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran
     (1, 2, 65536, 128, torch.float16, "HND", True, True, 64, "per_thread"),       # 128 slabs: the longest head the barrier takes
     (1, 1, 65536 - 300, 64, torch.bfloat16, "NHD", True, False, 64, "per_warp"),
     (1, 2, 1, 64, torch.float16, "HND", True, True, 64, "per_thread"),
+    # the Triton-named API's K convention: per-block scales, Triton rounding (an all-zero block has scale 0)
+    (2, 4, 1024, 128, torch.bfloat16, "HND", True, False, 64, "per_block_triton"),
+    (1, 3, 777, 64, torch.float16, "NHD", False, False, 64, "per_block_triton"),
+    (1, 2, 5000, 128, torch.float16, "NHD", True, True, 64, "per_block_triton"),
 ]
 
 
@@ -69,6 +75,31 @@ def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth
             _same(a, b, f"{name} (call {rep})")
     assert quant.prepass_failed_heads(sync, B, H) == 0
     assert int(sync.abs().sum().item()) == 0           # counters re-armed by the kernel, no give-up flag
+
+
+def test_triton_api_one_launch_prepass_is_bit_identical():
+    """sageattn_qk_int8_pv_fp16_triton through the one-launch pre-pass (K mean + Triton-rounded per-block INT8 K + fp16 V image) against the
+    kernel sequence, incl. an all-zero K block (scale 0 -> INT8 zeros, as the stand-alone quantiser gives) and the masked kernels."""
+    import sageattention_amd as sa
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (B, Hq, Hkv, L, D, dt, layout) in [(2, 8, 4, 1500, 128, torch.bfloat16, "HND"), (1, 4, 4, 640, 64, torch.float16, "NHD")]:
+        shp = (lambda h: (B, h, L, D)) if layout == "HND" else (lambda h: (B, L, h, D))
+        q = torch.randn(shp(Hq), device="cuda", generator=g).to(dt)
+        k = (torch.randn(shp(Hkv), device="cuda", generator=g) + 0.7).to(dt)
+        v = torch.randn(shp(Hkv), device="cuda", generator=g).to(dt)
+        for smooth_k in (True, False):
+            if not smooth_k:
+                (k[:, :, 64:128] if layout == "HND" else k[:, 64:128]).zero_()
+            for causal in (False, True):
+                a, la = sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, is_causal=causal, smooth_k=smooth_k, return_lse=True,
+                                                           fused_prepass=True)
+                b, lb = sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, is_causal=causal, smooth_k=smooth_k, return_lse=True,
+                                                           fused_prepass=False)
+                assert torch.isfinite(a.float()).all()
+                _same(a, b, "o"); _same(la, lb, "lse")
+        mask = torch.rand(B, Hq, L, L, device="cuda", generator=g) > 0.3
+        _same(sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, attn_mask=mask, fused_prepass=True),
+              sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, attn_mask=mask, fused_prepass=False), "masked o")
 
 
 def test_k_half_only_and_side_stream():
