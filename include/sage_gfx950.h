@@ -168,7 +168,9 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
 /*
  * The whole K / V pre-pass of the FP8-PV entry points as ONE launch that reads K and V once (2 B/elt in, 1 B/elt out):
  *   K: km = k.mean(dim=seq) (core.py:280) -> k_mean [B,H,D] (input dtype), INT8 (k - km) + group scales as
- *      sage_quant_qk_int8 writes them for is_key = 1, blk = warp = k_blk, qk_quant_gran per-block or per-thread;
+ *      sage_quant_qk_int8 writes them for is_key = 1, blk = warp = k_blk, qk_quant_gran per-block or per-thread; k_style: the CUDA
+ *      convention or the per-thread Triton one (the reference's CUDA entry points), or SAGE_QSTYLE_TRITON with per-block scales (its
+ *      Triton-named API, quant_per_block.py:21-46);
  *      k_mean == NULL: no smoothing (smooth_k = False)
  *   V: v_image / v_scale / v_mean exactly as sage_prep_v_fp8 (v_mean != NULL => smooth_v); v_fp16 != 0: the fp16 image of
  *      sage_prep_v_f16 instead (`v.to(float16)`, core.py:297-298,613; no statistics, v_scale / v_mean unused)
