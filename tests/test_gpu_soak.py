@@ -146,3 +146,32 @@ def test_causal_work_order_does_not_change_a_bit(route, shape):
             assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1]) and torch.equal(o2, outs[0][2]), f"order {order} differs"
     finally:
         route.sage_set_work_order(old)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_200_launches_on_two_streams_are_bit_identical(route, causal):
+    """sageattn_varlen's default route: index arrays from sage_varlen_plan, per-block Q quantised in the attention prologue (a workgroup-wide
+    abs-max through LDS before the first tile), K / V halves as separate kernels -- every launch equals the first one bit for bit."""
+    lens = [2048, 1, 640, 129, 3000, 64, 1500, 777]
+    total = sum(lens)
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(total, 8, 128, generator=g).to(BF16).to(DEV)
+    k = (torch.randn(total, 4, 128, generator=g) + torch.randn(1, 4, 128, generator=g)).to(BF16).to(DEV)
+    v = torch.randn(total, 4, 128, generator=g).to(BF16).to(DEV)
+    cu = torch.nn.functional.pad(torch.tensor(lens).cumsum(0), (1, 0)).to(torch.int32).to(DEV)
+    fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal)
+    first = fn()
+    torch.cuda.synchronize()
+    assert torch.isfinite(first.float()).all()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    bad = 0
+    for i in range(100):
+        with torch.cuda.stream(side):
+            if i % 4 == 0:
+                (a @ a).sum()
+            o2 = fn()
+        o1 = fn()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(o1, first)) + int(not torch.equal(o2, first))
+    assert bad == 0, f"{bad} of 200 varlen launches differ from the first"
