@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 16
+#define SAGE_ABI_VERSION 17
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -70,19 +70,13 @@ extern "C" {
 SAGE_API int sage_abi_version(void);
 SAGE_API const char *sage_last_error(void);
 
-/* Kernel route of the dense FP8-PV, head_dim 128 attention entry points (sage_attn_qk_int8_pv_f8, sage_attn_fused_q_pv_f8).
- * -1 (default): by shape -- today always the 128-row kernel (the 256-row workgroup kernel, one wave per SIMD, sage_attn64.hip,
- * measured 12-17 % slower at every size); 0: always the 128-row kernel; 1: the 256-row kernel wherever it is eligible.
- * Both kernels implement the same reference kernels (csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:46-704) with the same operand
- * order; the switch exists for A/B measurements and tests.  Process-wide; initialised from the environment variable SAGE_ATTN64. */
-SAGE_API int sage_attn64_mode(void);
-SAGE_API void sage_set_attn64_mode(int mode);
-
 /* Work order of causal dense launches of the 128-row kernels (which (head, query block) item workgroup blockIdx takes; results do
  * not depend on it).  -1 (default): heads in groups sized by the grid, longest query blocks of a group first, single-round grids
  * folded so that a CU's two workgroups are a long and a short block; 0: head-major, longest block of each head first (rounds 1-2);
  * n > 0: groups of n heads.  The reference launches blockIdx.x = query block in ascending order (qk_int_sv_f8_cuda_sm89.cuh:720-738)
- * and leaves the order to the hardware.  Process-wide; initialised from the environment variable SAGE_ORDER_GROUP. */
+ * and leaves the order to the hardware.  DEBUG / A-B SWITCH, not part of the data path's contract: one process-wide integer, initialised from the
+ * environment variable SAGE_ORDER_GROUP, read by every later launch; NOT thread-safe against concurrent launches (set it before the first call
+ * or not at all).  Apart from this switch and sage_debug_prepass_fail (a test hook) the library keeps no state between calls. */
 SAGE_API int sage_work_order(void);
 SAGE_API void sage_set_work_order(int group);
 /* Host-side views of that order (csrc/sage_work_order.h, the code the kernels and launchers run; no GPU needed): the plan of a causal
@@ -115,13 +109,30 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
                        int blk, int warp, int gran, int is_key, int style,
                        float pre_scale, int dtype, void *stream);
 
-/* The index arrays of a packed-batch call in one launch: cu_q_scale / cu_k_scale = exclusive prefix sums of ceil(L_i / blkq) and
- * ceil(L_i / blkk) (nseq + 1 entries each; cu_q_scale nullable), seq_order = the sequences by descending query length (the attention
- * launcher's processing order; results do not depend on it).  nseq <= sage_varlen_plan_max_seqs().
- * Replaces: the torch prefix sums of quant_per_block_varlen.py:68-73. */
+/* Every index array of a packed-batch (varlen) call from ONE small launch, so that the call never synchronises with the host:
+ *   cu_q_scale / cu_k_scale  exclusive prefix sums of ceil(Lq_i / blkq), ceil(Lk_i / blkk) (nseq + 1 entries; cu_q_scale nullable)
+ *   seq_order   (nullable) the sequences by descending query length: the unit order of an attention launch WITHOUT a work list
+ *   work_items  (nullable) the work list of the attention launch: (sequence, 128-row query block) int32 pairs for every query block that
+ *               exists, sorted by descending weight = 64-key tiles the block visits under `is_causal` (ties: sequence index, then the
+ *               later block first); the caller allocates 2 * (ceil(sum Lq / 128) + nseq) ints, a host-known bound of the count
+ *   slab_first / slab_seq  (nullable, together) the 512-token slabs of sage_prepass_kv_varlen: prefix sums of ceil(Lk_i / 512)
+ *               (nseq + 1) and slab -> sequence (caller allocates ceil(sum Lk / 512) + nseq ints)
+ *   hdr         (needed by work_items / slab_seq) 8 ints: number of work items, then the launch plan over them as for a dense causal
+ *               launch of Hq heads (csrc/sage_work_order.h: heads per group -- whole GQA groups --, fold, left-over heads), the number
+ *               of slabs, max Lk, sum Lk, 0
+ * Results of the attention launch do not depend on either order.  nseq <= sage_varlen_plan_max_seqs(); work_items needs blkq = 128, blkk = 64.
+ * Replaces: the torch prefix sums of quant_per_block_varlen.py:68-73 and the `.item()` synchronisations of :75-76; the reference launches
+ * ceil(max_seqlen_q / 128) blocks for EVERY sequence and lets the ones past a sequence's end exit (attn_qk_int8_block_varlen.py:98-121). */
 SAGE_API int sage_varlen_plan_max_seqs(void);
 SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
-                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order, void *stream);
+                              int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
+                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
+                              int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream);
+/* Host-side view of that work list (the same functions of csrc/sage_work_order.h, run on the host; no GPU needed): lq / lk are HOST arrays of
+ * the nseq sequence lengths; items_out receives (sequence, query block) pairs, hdr_out {count, group, fold, left}; returns the grid size of
+ * the attention launch or a negative status. */
+SAGE_API int sage_debug_varlen_items(const int32_t *lq, const int32_t *lk, int nseq, int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
+                                     int32_t *items_out, int items_cap, int32_t *hdr_out);
 
 /*
  * Same for packed variable-length batches x[sum L, H, D] (per-block only).
@@ -188,11 +199,27 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *   L     at most sage_prepass_max_seqlen() (65536 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
  *         head wait for each other inside the launch, so all of them must fit on the device at once; longer
  *         sequences take the three-call sequence (SAGE_EINVAL here).  The bound uses the compute units `stream` may use
- *         (hipExtStreamGetCUMask).  Per head, ((ceil(L/512)*512 - 1) * row stride + D) * 2 must stay below 2^32.
+ *         (hipExtStreamGetCUMask): sage_prepass_max_seqlen_stream(stream) is that bound.  Per head, ((ceil(L/512)*512 - 1) * row
+ *         stride + D) * 2 must stay below 2^32.
+ *   host_flag  nullable: a device-visible pinned HOST word (hipHostMalloc).  A workgroup that gives up also stores 1 there
+ *         (system scope), so the caller can notice a poisoned launch at its next call without synchronising -- the Python layer
+ *         then warns and routes the device's later calls through the three-call sequence.  What the bound above cannot see is
+ *         compute units held by OTHER streams' kernels (e.g. RCCL) for longer than the ~1 s wait.
  */
+/* K-smoothing mean of a packed batch x[sum L, H, D] over ALL tokens (core.py:432-434) -> mean_out [H, D], summed over the per-sequence
+ * 512-token slabs of sage_varlen_plan (slab_first / slab_seq / hdr) -- the partition, hence the bits, of sage_prepass_kv_varlen.
+ * ws: sage_stats_ws_floats(1, H, 512 * nslab_bound, D) floats. */
+SAGE_API int sage_channel_mean_varlen(const void *x, void *mean_out, float *ws, const int32_t *cu_seqlens, const int32_t *slab_first,
+                                      const int32_t *slab_seq, const int32_t *hdr, int total_tokens, int nslab_bound, int H, int D,
+                                      int64_t x_sl, int64_t x_sh, int dtype, void *stream);
 SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D);
 SAGE_API int64_t sage_prepass_sync_words(int B, int H);
 SAGE_API int sage_prepass_max_seqlen(void);
+SAGE_API int sage_prepass_max_seqlen_stream(void *stream);
+/* One device-visible word of pinned host memory (zeroed) for `host_flag`: *host_ptr for the host's reads, *device_ptr for the kernels.
+ * Owned by the caller (sage_host_word_free); the library keeps no handle to it. */
+SAGE_API int sage_host_word_alloc(void **host_ptr, void **device_ptr);
+SAGE_API int sage_host_word_free(void *host_ptr);
 SAGE_API int sage_prepass_failed_heads(const uint32_t *sync, int B, int H, void *stream);
 /* test hook: non-zero makes every following sage_prepass_kv launch wait for a slab that does not exist and give up after
  * 2^10 polls, i.e. exercises the give-up path above (process-wide; reset with 0) */
@@ -202,7 +229,26 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
                     int B, int H, int L, int D,
                     int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
-                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, void *stream);
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, uint32_t *host_flag, void *stream);
+
+/* The K / V pre-pass of sageattn_varlen (core.py:431-444) as ONE launch that reads K and V once: packed k / v [sum L, H, D];
+ *   K: km = k.mean(dim=0) over ALL packed tokens -> k_mean [H, D] (input dtype; NULL: no smoothing), then per sequence the INT8
+ *      (k - km) rows and one scale per 64 keys with the Triton rounding, k_scale [cu_k_scale[nseq], H] -- the bits of
+ *      sage_channel_mean (over the same slabs) + sage_quant_qk_int8_varlen;
+ *   V: the fp16 tile image [cu_k_scale[nseq], H, D, 64] of sage_prep_v_f16_varlen (v NULL: K half only).
+ * A slab is 512 tokens of ONE sequence (so scale blocks and V tiles never straddle slabs); cu_k_scale, slab_first, slab_seq and hdr come
+ * from sage_varlen_plan.  nslab_bound = the host-known bound ceil(total_tokens / 512) + nseq sizes the grid and the workspace
+ * (ws: 2 * H * nslab_bound * 3 * D floats = sage_prepass_ws_floats(1, H, 512 * nslab_bound, D); sync: sage_prepass_sync_words(1, H)).
+ * With k_mean the slabs of a head -- all sequences -- wait for each other inside the launch: nslab_bound must not exceed 128 nor the compute
+ * units `stream` may use (SAGE_EINVAL otherwise: take the three-call sequence).  Giving up is loud as for sage_prepass_kv (NaN k scales). */
+SAGE_API int sage_prepass_kv_varlen(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale, void *v_image,
+                                    float *ws, uint32_t *sync, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
+                                    const int32_t *slab_first, const int32_t *slab_seq, const int32_t *hdr,
+                                    int nseq, int total_tokens, int max_seqlen_k, int nslab_bound, int H, int D,
+                                    int64_t k_sl, int64_t k_sh, int64_t v_sl, int64_t v_sh, int64_t ko_sl, int64_t ko_sh,
+                                    int dtype, uint32_t *host_flag, void *stream);
+/* test hook: nwg workgroups of 1024 threads spin for ms milliseconds on `stream` (two of them fill a compute unit's wave slots) */
+SAGE_API int sage_debug_spin(int ms, int nwg, void *stream);
 
 /* V pre-pass, FP16: (bf16 -> fp16) + transpose into the tile image.  Replaces `v.to(float16)`
  * (core.py:297-298,613) and, with v_mean != NULL ([B,H,D] fp32 to subtract), sub_mean_cuda
@@ -278,12 +324,16 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
 /* Variable-length fused attention (per-block scales, FP16 PV), packed q/o [sum Lq, Hq, D],
  * k [sum Lk, Hkv, D].  Replaces: attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125.
  * cu_q_scale / cu_k_scale: prefix sums of ceil(Lq_i/128) / ceil(Lk_i/64) (also the V tile prefix).
- * seq_order (nullable, device int32[nseq]): a permutation of the sequence indices giving the order in which the
- * launch schedules them -- longest first shortens the tail; results do not depend on it. */
+ * Work order, either of (results do not depend on it):
+ *   work_items / work_hdr / items_bound  the work list and header of sage_varlen_plan and the host-known bound of the item count that sized
+ *              work_items (ceil(sum Lq / 128) + nseq): every workgroup takes one existing query block, heaviest first, GQA groups per XCD;
+ *   seq_order  (without a work list; nullable, device int32[nseq]) a permutation of the sequence indices: (sequence, kv-head) units are
+ *              dealt to the XCDs in that order, ceil(max_seqlen_q / 128) blocks per unit, the ones past a sequence's end exit. */
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
                                     const float *q_scale, const float *k_scale,
                                     const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                                     const int32_t *cu_q_scale, const int32_t *cu_k_scale, const int32_t *seq_order,
+                                    const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                     int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh,
                                     int64_t o_sl, int64_t o_sh,
@@ -328,7 +378,8 @@ SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const
  * Replaces: quant_per_block_varlen.py:60-104 (the q half, core.py:436-439) + attn_qk_int8_block_varlen.py forward. */
 SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
                                                   const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
-                                                  const int32_t *seq_order, int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                                  const int32_t *seq_order, const int32_t *work_items, const int32_t *work_hdr, int items_bound,
+                                                  int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                                   int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
                                                   int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream);
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 16
+ABI_VERSION = 17
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -28,8 +28,6 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SYMBOLS = {
     "sage_abi_version": (c_int, []),
     "sage_last_error": (ctypes.c_char_p, []),
-    "sage_attn64_mode": (c_int, []),
-    "sage_set_attn64_mode": (None, [_I]),
     "sage_debug_work_order_plan": (c_int, [_I, _I, _L, _I, _I, _I, _P, _P, _P]),
     "sage_debug_work_item": (c_int, [_I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sage_work_order": (c_int, []),
@@ -41,14 +39,21 @@ SYMBOLS = {
                                           _I, _F, _I, _P]),
     "sage_stats_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_channel_mean": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "sage_channel_mean_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
     "sage_prep_v_fp8": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
     "sage_prepass_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_prepass_sync_words": (c_int64, [_I, _I]),
     "sage_prepass_max_seqlen": (c_int, []),
+    "sage_prepass_max_seqlen_stream": (c_int, [_P]),
+    "sage_host_word_alloc": (c_int, [_P, _P]),
+    "sage_host_word_free": (c_int, [_P]),
     "sage_prepass_failed_heads": (c_int, [_P, _I, _I, _P]),
     "sage_debug_prepass_fail": (None, [_I]),
     "sage_prepass_kv": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
-                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
+    "sage_prepass_kv_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                       _L, _L, _L, _L, _L, _L, _I, _P, _P]),
+    "sage_debug_spin": (c_int, [_I, _I, _P]),
     "sage_prep_v_f16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
     "sage_prep_v_f16_varlen": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
     "sage_attn_qk_int8_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
@@ -57,17 +62,18 @@ SYMBOLS = {
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
     "sage_attn_qk_int8_pv_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P]),
-    "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+    "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_attn_fused_q_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_attn_fused_q_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_varlen_plan_max_seqs": (c_int, []),
-    "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sage_debug_varlen_items": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sage_attn_fused_qblock_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
-    "sage_attn_fused_qblock_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+    "sage_attn_fused_qblock_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                                      _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_attn_fused_q_pv_f8_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),

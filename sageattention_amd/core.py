@@ -22,11 +22,12 @@ import torch
 import torch.nn.functional as F
 
 from . import _cabi, ops
-from .quant import (LOG2E, _aligned, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
-                    per_channel_fp8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, sub_mean, varlen_plan)
+from .quant import (LOG2E, _aligned, _cu_blocks, _dims, _p, _quant, _squeeze_km, _stream, channel_mean, channel_mean_packed, per_block_int8, per_block_int8_varlen,
+                    per_channel_fp8, prep_v_fp16, prep_v_fp16_varlen, prepass_fused_ok, prepass_kv_fp8, prepass_kv_varlen,
+                    prepass_varlen_fused_ok, sub_mean, varlen_plan)
 
 _SUPPORTED_ARCH_PREFIX = "gfx950"
-_FUSE_Q16_DEFAULT = __import__("os").environ.get("SAGE_FUSE_Q16", "1") != "0"      # debugging switch
+_FUSE_Q16_DEFAULT = os.environ.get("SAGE_FUSE_Q16", "1") != "0"      # debugging switch
 
 
 def get_gcn_arch(device: torch.device) -> str:
@@ -317,50 +318,100 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
+class _VarlenState:
+    """Operands of the attention launch of one ``sageattn_varlen`` call (what its pre-pass produces)."""
+    __slots__ = ("q", "q_int8", "q_scale", "k_int8", "k_scale", "v_image", "cu_q", "cu_k", "cu_qs", "cu_ks", "order", "plan", "fuse_q",
+                 "max_seqlen_q", "is_causal", "q_premul", "dtype", "head_dim_og")
+
+
 @torch.compiler.disable
-def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, is_causal: bool = False,
-                    sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any) -> torch.Tensor:
-    """Variable-length batches, q/k/v packed as ``[sum L, H, D]`` (reference core.py:334-448)."""
-    dtype = q.dtype
+def _varlen_prepare(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal, sm_scale, smooth_k, kwargs) -> _VarlenState:
+    """Everything of ``sageattn_varlen`` in front of the attention launch (core.py:427-444): the index arrays (one launch, no host
+    synchronisation), ``km`` over all packed tokens, INT8 K, the fp16 V image -- one launch that reads K and V once where the head barrier
+    reaches (``prepass_kv_varlen``), else the kernel sequence with the same bits."""
+    st = _VarlenState()
+    st.dtype = q.dtype
     _check_inputs(q, k, v)
     torch.cuda.set_device(v.device)
-    q, k, v, head_dim_og = _pad_head_dim(q, k, v)
+    q, k, v, st.head_dim_og = _pad_head_dim(q, k, v)
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
     assert cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous(), "cu_seqlens_q and cu_seqlens_k must be contiguous."
     Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[2]
     assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
-    km = channel_mean_packed(k) if smooth_k else None   # mean over ALL packed tokens, as core.py:432-434
     if sm_scale is None:
-        sm_scale = 1.0 / (head_dim_og ** 0.5)
-    fuse_q = kwargs.get("fuse_q_quant", True)      # the Q half of the quantiser in the attention kernel's prologue (same bits)
-    cu_q = cu_seqlens_q.to(torch.int32).contiguous()
-    cu_k = cu_seqlens_k.to(torch.int32).contiguous()
-    # fused route: block-count prefix sums and the longest-first processing order from one small launch, no host synchronisation (the
-    # reference sizes its scale tensors with .item(); here they are allocated at a bound known on the host)
-    plan = varlen_plan(cu_q, cu_k) if fuse_q else None
-    q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks = per_block_int8_varlen(
-        None if fuse_q else q, k, cu_q, cu_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale,
-        cu_ks=plan[1] if plan is not None else None)
+        sm_scale = 1.0 / (st.head_dim_og ** 0.5)
+    st.fuse_q = fuse_q = kwargs.get("fuse_q_quant", True)      # the Q half of the quantiser in the attention kernel's prologue (same bits)
+    st.cu_q = cu_q = cu_seqlens_q.to(torch.int32).contiguous()
+    st.cu_k = cu_k = cu_seqlens_k.to(torch.int32).contiguous()
     nseq = cu_q.shape[0] - 1
-    v_image = prep_v_fp16_varlen(v, cu_k, cu_ks, max_seqlen_k, ntiles=((k.shape[0] + 63) // 64 + nseq) if fuse_q else None)
-    o = torch.empty(q.shape, dtype=dtype, device=q.device)
-    code = _cabi.DTYPE_F16 if dtype == torch.float16 else _cabi.DTYPE_BF16
-    # schedule the longest sequences first (on the device, no sync); results do not depend on the order
-    order = plan[2] if plan is not None else torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
-    if fuse_q:
-        q = _aligned(q, 8)
+    # block-count prefix sums, the attention launch's work list and the pre-pass's slab map from one small launch (None: more sequences than
+    # it takes -- then torch prefix sums, an on-device argsort for the order and the kernel sequence)
+    plan = varlen_plan(cu_q, cu_k, want_q_blocks=not fuse_q, total_q=q.shape[0], total_k=k.shape[0], is_causal=is_causal, Hq=Hq, Hkv=Hkv,
+                       head_dim=D, pv_fp8=False) if kwargs.get("varlen_plan", True) else None
+    st.plan = plan if (plan is not None and kwargs.get("work_list", True)) else None
+    fused = kwargs.get("fused_prepass")
+    if fused is None:
+        fused = os.environ.get("SAGE_PREPASS", "") not in ("seq", "sequence", "0")
+    fused = bool(fused) and k.shape == v.shape and prepass_varlen_fused_ok(k, plan, max_seqlen_k, smooth_k)
+    if fused:
+        _, st.k_int8, st.k_scale, st.v_image = prepass_kv_varlen(k, v, cu_k, plan, max_seqlen_k, smooth_k=smooth_k)
+        st.cu_ks = plan.cu_ks
+        st.q_int8 = st.q_scale = st.cu_qs = None
+        if not fuse_q:
+            st.q_int8, st.q_scale, _, _, st.cu_qs, _ = per_block_int8_varlen(q, None, cu_q, cu_k, max_seqlen_q, max_seqlen_k, sm_scale=sm_scale,
+                                                                            cu_qs=plan.cu_qs)
+    else:
+        km = channel_mean_packed(k, cu_k, plan) if smooth_k else None   # mean over ALL packed tokens, as core.py:432-434
+        # (prefix arrays from the plan, or from torch ops on the device: either way the scale tensors are allocated at their host-known
+        #  bounds and nothing synchronises -- the reference's `.item()` pair is gone on every route)
+        st.q_int8, st.q_scale, st.k_int8, st.k_scale, st.cu_qs, st.cu_ks = per_block_int8_varlen(
+            None if fuse_q else q, k, cu_q, cu_k, max_seqlen_q, max_seqlen_k, km=km, sm_scale=sm_scale,
+            cu_ks=plan.cu_ks if plan is not None else _cu_blocks(cu_k, 64),
+            cu_qs=None if fuse_q else (plan.cu_qs if plan is not None else _cu_blocks(cu_q, 128)))
+        st.v_image = prep_v_fp16_varlen(v, cu_k, st.cu_ks, max_seqlen_k, ntiles=(k.shape[0] + 63) // 64 + nseq)
+    # without a work list: schedule the longest sequences first (on the device, no sync); results do not depend on the order
+    st.order = plan.order if plan is not None else torch.argsort(cu_q[1:] - cu_q[:-1], descending=True).to(torch.int32)
+    st.q = _aligned(q, 8) if fuse_q else None
+    st.max_seqlen_q, st.is_causal, st.q_premul = int(max_seqlen_q), bool(is_causal), float(sm_scale * LOG2E)
+    return st
+
+
+@torch.compiler.disable
+def _varlen_attend(st: _VarlenState) -> torch.Tensor:
+    """The attention launch of ``sageattn_varlen`` (attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125)."""
+    q = st.q if st.fuse_q else st.q_int8
+    Hq, D = q.shape[1], q.shape[2]
+    Hkv = st.k_int8.shape[1]
+    o = torch.empty(q.shape, dtype=st.dtype, device=q.device)
+    code = _cabi.DTYPE_F16 if st.dtype == torch.float16 else _cabi.DTYPE_BF16
+    plan = st.plan
+    items, hdr, bound = (plan.items, plan.hdr, plan.items_bound) if plan is not None else (None, None, 0)
+    nseq = st.cu_q.shape[0] - 1
+    if st.fuse_q:
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
-            _p(q), _p(k_int8), _p(v_image), _p(o), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_ks), _p(order),
-            cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q.stride(0), q.stride(1), k_int8.stride(0), k_int8.stride(1),
-            o.stride(0), o.stride(1), int(is_causal), float(sm_scale * LOG2E), code, code, _stream(o))
+            _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_ks), _p(st.order),
+            _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1), st.k_int8.stride(0), st.k_int8.stride(1),
+            o.stride(0), o.stride(1), int(st.is_causal), st.q_premul, code, code, _stream(o))
         _cabi.check(rc, "sage_attn_fused_qblock_pv_f16_varlen")
-        return o[..., :head_dim_og]
-    rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
-        _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(q_scale), _p(k_scale), _p(cu_q), _p(cu_k), _p(cu_qs), _p(cu_ks),
-        _p(order), cu_q.shape[0] - 1, int(max_seqlen_q), Hq, Hkv, D, q_int8.stride(0), q_int8.stride(1), k_int8.stride(0), k_int8.stride(1),
-        o.stride(0), o.stride(1), int(is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o))
-    _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
-    return o[..., :head_dim_og]
+    else:
+        rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
+            _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.q_scale), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_qs), _p(st.cu_ks),
+            _p(st.order), _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1),
+            st.k_int8.stride(0), st.k_int8.stride(1), o.stride(0), o.stride(1), int(st.is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o))
+        _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
+    return o[..., :st.head_dim_og]
+
+
+@torch.compiler.disable
+def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, is_causal: bool = False,
+                    sm_scale: Optional[float] = None, smooth_k: bool = True, **kwargs: Any) -> torch.Tensor:
+    """Variable-length batches, q/k/v packed as ``[sum L, H, D]`` (reference core.py:334-448).  Three launches and no host
+    synchronisation on the default route: the index arrays (``sage_varlen_plan``), the K / V pre-pass (``sage_prepass_kv_varlen``) and
+    the attention kernel over a device-built work list (every workgroup one existing query block, heaviest first) with the per-block Q
+    quantisation in its prologue.  Route switches (same bits either way): ``fused_prepass=False`` the kernel sequence,
+    ``work_list=False`` the unit order sized by ``max_seqlen_q``, ``fuse_q_quant=False`` a separate Q quantiser."""
+    return _varlen_attend(_varlen_prepare(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal, sm_scale, smooth_k,
+                                          kwargs))
 
 
 _ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant")

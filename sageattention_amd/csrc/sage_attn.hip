@@ -74,6 +74,11 @@
 #ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
 #define SAGE_ORDER_DEFAULT -1
 #endif
+#ifndef SAGE_FOLDBIAS   // pipelined loops: the bias of the score's bit pattern (SAGE_MAGIC) is removed inside the scale FMA,
+#define SAGE_FOLDBIAS 1 // exp2(fma(bits, c, -(m + bias * c))), instead of by a v_add_f32 of its own per score (32 VALU instructions of ~195
+#endif                  // per wave-tile).  m + bias * c is rounded once per (row, tile, k scale): an error of <= 0.64 of ONE integer step of the
+                        // INT8 x INT8 score in the exponent (2^-24 * 0.159 * 2^26 * dequantisation scale), against a quantisation noise of
+                        // ~ 10^2 steps; 0 = the separate, exact subtraction (bit-identical to rounds 2-3)
 #ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
 #define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
 #endif
@@ -82,7 +87,7 @@
                         // score tiles at D=128 (248 VGPRs: 2 waves; measured equal to 3 waves for the phased loop); D=64 fits 3 (167).
                         // Phased loops: 3 (<= 168 VGPRs, +3.5% measured) wherever that does not spill.
 #define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) \
-    ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : ((PV_FP8) ? ((SAGE_PIPE && SAGE_MAGIC && (!(TWO_LEVEL) || SAGE_DIRECT)) ? 2 : (((TWO_LEVEL) || !(KTHREAD)) ? 3 : 2)) : 2)))
+    ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : ((PV_FP8) ? (((SAGE_PIPE != 0) && (SAGE_MAGIC != 0) && (!(TWO_LEVEL) || (SAGE_DIRECT != 0))) ? 2 : (((TWO_LEVEL) || !(KTHREAD)) ? 3 : 2)) : 2)))
 #endif
 
 namespace sage {
@@ -154,8 +159,24 @@ sage_attn_kernel(const AttnParams p)
     // ---- work item: XCD-aware, heavy-first --------------------------------------------------
     const int nqblk = p.nqblk;
     int b, h, hk, qblk;
-    if (p.cu_q != nullptr) {
-        // varlen: sequences differ in length, so a contiguous run per XCD would hand one XCD the longest sequence
+    if (p.cu_q != nullptr && p.work_items != nullptr) {
+        // varlen with the device-built work list (sage_varlen_plan): the query blocks of all sequences are one item list per query head,
+        // heaviest first, and the launch is a dense launch over Hq heads of `nitems` items each (sage_work_order.h) -- whole GQA groups
+        // stay on one XCD, every workgroup has an item (the grid is sized by a host-known bound of nitems; the few past it exit here)
+        typedef const __attribute__((address_space(4))) int *cint_p;          // wave-uniform: scalar loads
+        const cint_p hdr = (cint_p)p.work_hdr;
+        const int nitems = hdr[0];
+        const WorkOrder wo = {hdr[1], hdr[2], hdr[3]};
+        const int nwg = 8 * (wo.left * ((nitems + 7) >> 3) + (p.Hq >> 3) * nitems);
+        int qrank;
+        if ((int)blockIdx.x >= nwg || !work_item(wo, blockIdx.x, nwg, p.Hq, nitems, h, qrank)) return;
+        const cint_p items = (cint_p)p.work_items;
+        b = items[2 * qrank];
+        qblk = items[2 * qrank + 1];
+        hk = h / p.group;
+    } else if (p.cu_q != nullptr) {
+        // varlen without a work list (more sequences than sage_varlen_plan takes): sequences differ in length, so a contiguous run
+        // per XCD would hand one XCD the longest sequence
         // (measured 3.5x slower on lengths 256..16384).  XCDs take (sequence, kv-head) units round-robin instead;
         // inside a unit the `group` query heads that share the K/V stream run heavy-first, interleaved.
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
@@ -798,7 +819,13 @@ sage_attn_kernel(const AttnParams p)
             // order O = O*alpha + P V, which the FP32 MFMA accumulator makes equivalent to the two-level fold.
             // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
             // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
-#define A_SUBC(d, a)       asm volatile("v_add_f32 %0, 0xbe22f983, %1" : "=v"(d) : "v"(a))
+// two scores d0 / d1 from the bit patterns s0 / s1: d = s * c - m (operands as asm placeholders; m = mb0 / mb1 above)
+#if SAGE_FOLDBIAS
+#define SAGE_SCALE2(d0, d1, s0, s1, c0, c1, m) "v_fma_f32 " d0 ", " s0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " s1 ", " c1 ", -" m "\n\t"
+#else
+#define SAGE_SCALE2(d0, d1, s0, s1, c0, c1, m) "v_add_f32 " d0 ", 0xbe22f983, " s0 "\n\tv_add_f32 " d1 ", 0xbe22f983, " s1 "\n\t" \
+                                                "v_fma_f32 " d0 ", " d0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " d1 ", " c1 ", -" m "\n\t"
+#endif
 #define A_FMAN(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
 #define A_EXP(d, a)        asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a))
 #define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
@@ -912,6 +939,13 @@ sage_attn_kernel(const AttnParams p)
                     const float m_new = fmaxf(m_run, pair_max(mxc));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
+#if SAGE_FOLDBIAS
+                    // what the scale FMA subtracts: the row maximum plus the bias of the score's bit pattern in this tile's scale
+                    const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
+                    const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
+#else
+                    const float mb0 = m_new, mb1 = m_new;
+#endif
                     if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
                     A_FENCE();
 #pragma unroll
@@ -928,12 +962,11 @@ sage_attn_kernel(const AttnParams p)
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
 #define SAGE_GRP(PACK)                                                                                                          \
-                        asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"                           \
-                                     "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"                                 \
+                        asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")                                        \
                                      "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
                                      "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t" PACK                                      \
                                      : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "+v"(pc[h >> 1])                               \
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new))
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"((KTHREAD && (i0 & 2)) ? mb1 : mb0))
                         if ((h & 1) == 0) SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3");
                         else SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
 #undef SAGE_GRP
@@ -955,13 +988,10 @@ sage_attn_kernel(const AttnParams p)
                     float u0, u1, u2, u3;
                     auto g4a = [&](int w) {
                         const int sb = w >> 2, i0 = 4 * (w & 3);
-                        asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
-                                     "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
-                                     "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
-                                     "v_fma_f32 %2, %2, %9, -%10\n\tv_fma_f32 %3, %3, %9, -%10\n\t"
+                        asm volatile(SAGE_SCALE2("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2("%2", "%3", "%6", "%7", "%9", "%9", "%11")
                                      "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"
                                      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(m_new));
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
                     };
                     auto g4b = [&](int w) {
                         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
@@ -1040,7 +1070,6 @@ sage_attn_kernel(const AttnParams p)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-#undef A_SUBC
 #undef A_FMAN
 #undef A_EXP
 #undef A_ACC
@@ -1176,6 +1205,12 @@ sage_attn_kernel(const AttnParams p)
                     const float m_new = fmaxf(m_run, pair_max(mxc));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
+#if SAGE_FOLDBIAS
+                    const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
+                    const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
+#else
+                    const float mb0 = m_new, mb1 = m_new;
+#endif
                     A_FENCE();
                     if constexpr (C::DT > 1) read_v(1, vfb);
                     A_FENCE();
@@ -1186,35 +1221,33 @@ sage_attn_kernel(const AttnParams p)
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
                         if constexpr (RSMFMA) {
-                            asm volatile("v_add_f32 %0, 0xbe22f983, %3\n\tv_add_f32 %1, 0xbe22f983, %4\n\t"
-                                         "v_fma_f32 %0, %0, %5, -%7\n\tv_fma_f32 %1, %1, %6, -%7\n\t"
+                            asm volatile(SAGE_SCALE2("%0", "%1", "%3", "%4", "%5", "%6", "%7")
                                          "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\t"
                                          "s_nop 0\n\tv_cvt_pk_f16_f32 %2, %0, %1"
                                          : "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
                         } else if constexpr (RSUM16) {
                             // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
                             // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
                             // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
                             // outputs 0.6-1.7 % too large on Lk = 333 with per-block scales).  The reference takes this sum from the
                             // tensor core (see tile_iter).
-                            asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
-                                         "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
+                            asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")
                                          "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
                                          "s_nop 0\n\tv_cvt_pk_f16_f32 %4, %2, %3\n\t"
                                          "v_fma_mix_f32 %0, %4, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
                                          "v_fma_mix_f32 %1, %4, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                                          : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
                         } else {
-                            asm volatile("v_add_f32 %2, 0xbe22f983, %5\n\tv_add_f32 %3, 0xbe22f983, %6\n\t"
-                                         "v_fma_f32 %2, %2, %7, -%9\n\tv_fma_f32 %3, %3, %8, -%9\n\t"
+                            asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")
                                          "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
                                          "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
                                          "v_cvt_pk_f16_f32 %4, %2, %3"
                                          : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(m_new));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
                         }
                     };
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
@@ -1346,6 +1379,7 @@ sage_attn_kernel(const AttnParams p)
                 }
             }
 #undef A_RS0
+#undef SAGE_SCALE2
 #undef A_PV16
 #undef A_QK0
 #undef A_QK
@@ -1504,28 +1538,6 @@ static hipError_t launch_fused_qblock_one(const AttnParams &p, int nwork, hipStr
     return launch_kernel(sage_attn_kernel<D, false, CAUSAL, false, true, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
 }
 
-// ---- route between the 128-row kernel family above and the 256-row one-wave-per-SIMD kernel (sage_attn64.hip) -------------
-static int g_attn64_mode = -2;       // -2: not read yet
-int attn64_mode()
-{
-    if (g_attn64_mode == -2) {
-        const char *e = getenv("SAGE_ATTN64");
-        g_attn64_mode = (e != nullptr && e[0] != 0) ? atoi(e) : -1;
-    }
-    return g_attn64_mode;
-}
-void set_attn64_mode(int mode) { g_attn64_mode = mode; }
-static bool use_attn64(const AttnParams &p, int head_dim, bool pv_fp8)
-{
-    if (!pv_fp8 || head_dim != 128 || p.cu_q != nullptr || p.kv_split > 1) return false;
-    const int mode = attn64_mode();
-    if (mode == 0) return false;
-    if (mode >= 1) return true;
-    // auto: the 128-row kernel.  Measured (profiles/r3_attn64_*): with one wave per SIMD every LDS-DMA issue, fragment read,
-    // scalar instruction and barrier wait of the wave is exposed, and the 256-row kernel runs 12-17 % behind at every size
-    return false;
-}
-
 // Causal dense grids: which (head, query block) item a workgroup takes -- sage_work_order.h (mapping, group-size rule, measurements).
 // Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first order over contiguous runs.
 // SAGE_ORDER_GROUP / sage_set_work_order: 0 restores the head-major order, n > 0 forces the group size (experiments).
@@ -1539,12 +1551,15 @@ int work_order()
     return g_work_order;
 }
 void set_work_order_mode(int group) { g_work_order = group; }
+static inline int nheads_of_varlen(const AttnParams &q) { return q.Hq; }
 static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8, bool masked)
 {
     q.order_group = 0;
     q.order_fold = 0;
     q.order_left = 0;
     const int nheads = q.B * q.Hq;
+    if (q.cu_q != nullptr && q.work_items != nullptr)             // varlen, device-built work list: bound of the dense-style grid over it
+        return 8 * ((nheads_of_varlen(q) & 7) * ((q.items_bound + 7) / 8) + (nheads_of_varlen(q) >> 3) * q.items_bound);
     if (q.cu_q != nullptr) return ((q.B * q.Hkv + 7) / 8) * 8 * q.group * q.nqblk;   // varlen: whole rounds of 8 (sequence, kv-head) units
     const int forced = work_order();
     if (!causal || masked || q.kv_split > 1 || q.nqblk <= 1 || forced == 0) return nheads * q.nqblk;
@@ -1563,7 +1578,6 @@ hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal
     const int nwork = set_work_order(p, causal, head_dim, pv_fp8, false);
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
-    if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, true, q_dtype == DT_F16 ? 1 : 2, stream);
 #define SAGE_FQ(D_, F_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, F_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 1>(p, nwork, stream); \
                              return causal ? launch_fused_q_one<D_, F_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 2>(p, nwork, stream); } while (0)
     if (head_dim == 128) { if (pv_fp8) SAGE_FQ(128, true); else SAGE_FQ(128, false); }
@@ -1600,7 +1614,6 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
         return mask_kind == 1 ? launch_masked<64, 1>(p, nwork, stream)
              : mask_kind == 2 ? launch_masked<64, 2>(p, nwork, stream) : launch_masked<64, 3>(p, nwork, stream);
     }
-    if (use_attn64(p, head_dim, pv_fp8)) return launch_attn64(p, head_dim, causal, kthread, 0, stream);
     // keys per iteration: 128 where two workgroups still fit a CU's LDS, else 64
     if (head_dim == 128) return pv_fp8 ? launch_d<128, true, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream)
                                        : launch_d<128, false, 1>(p, nwork, causal, kthread, two_level, stream);

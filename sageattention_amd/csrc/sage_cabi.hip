@@ -41,7 +41,8 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 int64_t o_sb, int64_t o_sh, int64_t o_sl,
                 int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream,
-                const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr)
+                const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr,
+                const int32_t *work_items = nullptr, const int32_t *work_hdr = nullptr, int items_bound = 0)
 {
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -64,6 +65,9 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
+    SAGE_REQUIRE((work_items == nullptr) == (work_hdr == nullptr) && (work_items == nullptr || (varlen && items_bound > 0)),
+                 "the work list comes as (work_items, work_hdr, items_bound > 0), varlen only");
+    p.work_items = work_items; p.work_hdr = work_hdr; p.items_bound = items_bound;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
     p.Lq = Lq; p.Lk = Lk;
     p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
@@ -110,8 +114,6 @@ extern "C" {
 
 SAGE_API int sage_abi_version(void) { return SAGE_ABI_VERSION; }
 SAGE_API const char *sage_last_error(void) { return g_err; }
-SAGE_API int sage_attn64_mode(void) { return sage::attn64_mode(); }
-SAGE_API void sage_set_attn64_mode(int mode) { sage::set_attn64_mode(mode < -1 ? -1 : (mode > 1 ? 1 : mode)); }
 // host-side views of sage_work_order.h (the code the kernels and launchers run), for tests without a GPU
 SAGE_API int sage_debug_work_order_plan(int nheads, int nqblk, int64_t kv_len, int head_dim, int pv_fp8, int forced, int *group, int *fold, int *left)
 {
@@ -123,7 +125,9 @@ SAGE_API int sage_debug_work_order_plan(int nheads, int nqblk, int64_t kv_len, i
 }
 SAGE_API int sage_debug_work_item(int bid, int nwg, int nheads, int nqblk, int group, int fold, int left, int *head, int *qrank)
 {
-    if (head == nullptr || qrank == nullptr || nwg <= 0 || bid < 0 || bid >= nwg) return fail(SAGE_EINVAL, "sage_debug_work_item: bad argument");
+    if (head == nullptr || qrank == nullptr || nwg <= 0 || bid < 0 || bid >= nwg || nheads <= 0 || nqblk <= 0 || group < 0 || fold < 0 || fold > 1 ||
+        left < 0 || left >= 8 || left > nheads)
+        return fail(SAGE_EINVAL, "sage_debug_work_item: bad argument");
     const sage::WorkOrder w = {group, fold, left};
     return sage::work_item(w, bid, nwg, nheads, nqblk, *head, *qrank) ? 1 : 0;
 }
@@ -199,13 +203,51 @@ SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *
 
 SAGE_API int sage_varlen_plan_max_seqs(void) { return sage::kVarlenPlanMaxSeq; }
 SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
-                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order, void *stream)
+                              int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
+                              int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
+                              int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream)
 {
-    SAGE_REQUIRE(cu_seqlens_q && cu_seqlens_k && cu_k_scale && seq_order, "null tensor pointer");
+    SAGE_REQUIRE(cu_seqlens_q && cu_seqlens_k && cu_k_scale, "null tensor pointer");
     SAGE_REQUIRE(nseq > 0 && nseq <= sage::kVarlenPlanMaxSeq, "nseq must be in 1 .. %d (got %d)", sage::kVarlenPlanMaxSeq, nseq);
     SAGE_REQUIRE(blkq > 0 && blkk > 0, "block sizes must be positive");
-    return check_launch(sage::launch_varlen_plan(cu_seqlens_q, cu_seqlens_k, nseq, blkq, blkk, cu_q_scale, cu_k_scale, seq_order,
-                                                 static_cast<hipStream_t>(stream)), "sage_varlen_plan launch");
+    SAGE_REQUIRE(work_items == nullptr || (hdr != nullptr && blkq == sage::BLKQ && blkk == sage::BLKK),
+                 "the work list needs hdr and the attention kernel's blocks (%d query rows, %d keys)", sage::BLKQ, sage::BLKK);
+    SAGE_REQUIRE(hdr == nullptr || (Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (head_dim == 64 || head_dim == 128)),
+                 "the launch plan needs Hq %% Hkv == 0 and head_dim 64 / 128 (got %d, %d, %d)", Hq, Hkv, head_dim);
+    SAGE_REQUIRE((slab_seq == nullptr) == (slab_first == nullptr) && (slab_seq == nullptr || hdr != nullptr), "slab_seq, slab_first and hdr come together");
+    sage::VarlenPlanParams p{};
+    p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k; p.nseq = nseq; p.blkq = blkq; p.blkk = blkk;
+    p.causal = is_causal ? 1 : 0; p.Hq = Hq > 0 ? Hq : 1; p.Hkv = Hkv > 0 ? Hkv : 1; p.head_dim = head_dim; p.pv_fp8 = pv_fp8 ? 1 : 0;
+    p.cu_qs = cu_q_scale; p.cu_ks = cu_k_scale; p.order = seq_order; p.items = work_items;
+    p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
+    return check_launch(sage::launch_varlen_plan(p, static_cast<hipStream_t>(stream)), "sage_varlen_plan launch");
+}
+// host-side view of the work list (csrc/sage_work_order.h, the functions varlen_plan_kernel runs; no GPU needed): lq / lk are HOST arrays of
+// the nseq sequence lengths; items_out receives 2 * nitems ints ((sequence, query block), heaviest first), hdr_out {nitems, group, fold, left};
+// returns the grid size of the launch, or a negative status
+SAGE_API int sage_debug_varlen_items(const int32_t *lq, const int32_t *lk, int nseq, int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
+                                     int32_t *items_out, int items_cap, int32_t *hdr_out)
+{
+    if (lq == nullptr || lk == nullptr || items_out == nullptr || hdr_out == nullptr || nseq <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 ||
+        (head_dim != 64 && head_dim != 128))
+        return fail(SAGE_EINVAL, "sage_debug_varlen_items: bad argument");
+    int nitems = 0, max_lk = 0;
+    for (int s = 0; s < nseq; s++) {
+        if (lq[s] < 0 || lk[s] < 0) return fail(SAGE_EINVAL, "sage_debug_varlen_items: negative length");
+        nitems += (lq[s] + 127) / 128;
+        max_lk = lk[s] > max_lk ? lk[s] : max_lk;
+    }
+    if (nitems > items_cap) return fail(SAGE_EINVAL, "sage_debug_varlen_items: %d items do not fit %d", nitems, items_cap);
+    for (int s = 0; s < nseq; s++)
+        for (int j = 0; j < (lq[s] + 127) / 128; j++) {
+            const int r = sage::varlen_item_rank(lq, lk, nseq, s, j, is_causal != 0);
+            if (r < 0 || r >= nitems) return fail(SAGE_ELAUNCH, "sage_debug_varlen_items: rank %d out of range", r);
+            items_out[2 * r] = s; items_out[2 * r + 1] = j;
+        }
+    sage::WorkOrder w;
+    const int grid = sage::plan_varlen_order(w, Hq, Hq / Hkv, nitems, (long)max_lk, head_dim, pv_fp8 != 0);
+    hdr_out[0] = nitems; hdr_out[1] = w.group; hdr_out[2] = w.fold; hdr_out[3] = w.left;
+    return grid;
 }
 
 static int stats_common(const void *x, void *mean_out, float *ws, float *stats, int B, int H, int L, int D,
@@ -253,6 +295,23 @@ SAGE_API int sage_channel_mean(const void *x, void *mean_out, float *ws, int B, 
 {
     SAGE_REQUIRE(mean_out, "null output pointer");
     return stats_common(x, mean_out, ws, nullptr, B, H, L, D, x_sb, x_sh, x_sl, dtype, stream, "sage_channel_mean launch");
+}
+
+SAGE_API int sage_channel_mean_varlen(const void *x, void *mean_out, float *ws, const int32_t *cu_seqlens, const int32_t *slab_first,
+                                      const int32_t *slab_seq, const int32_t *hdr, int total_tokens, int nslab_bound, int H, int D,
+                                      int64_t x_sl, int64_t x_sh, int dtype, void *stream)
+{
+    SAGE_REQUIRE(x && ws && mean_out && cu_seqlens && slab_first && slab_seq && hdr, "null tensor pointer");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(H > 0 && total_tokens > 0 && nslab_bound >= (total_tokens + sage::kStatsSlab - 1) / sage::kStatsSlab, "empty tensor or nslab_bound too small");
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    SAGE_REQUIRE(aligned16(x) && x_sl % 8 == 0 && x_sh % 8 == 0, "input must be 16-byte aligned with strides in multiples of 8 elements");
+    sage::StatsParams p{};
+    p.x = x; p.ws = ws; p.stats = nullptr; p.mean_out = mean_out;
+    p.B = 1; p.H = H; p.L = total_tokens; p.D = D; p.nslab = nslab_bound;
+    p.x_sb = 0; p.x_sh = x_sh; p.x_sl = x_sl; p.dtype = dtype;
+    p.cu = cu_seqlens; p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
+    return check_launch(sage::launch_stats(p, static_cast<hipStream_t>(stream)), "sage_channel_mean_varlen launch");
 }
 
 SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float *v_mean, float *ws,
@@ -313,6 +372,34 @@ SAGE_API int sage_prepass_max_seqlen(void)
     return cached_len;
 }
 
+// one device-visible word of pinned host memory for the `host_flag` argument below (owned by the caller: the library keeps no handle)
+SAGE_API int sage_host_word_alloc(void **host_ptr, void **device_ptr)
+{
+    SAGE_REQUIRE(host_ptr && device_ptr, "null output pointer");
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { if (h) (void)hipHostFree(h); return fail(SAGE_ELAUNCH, "sage_host_word_alloc: %s", hipGetErrorString(e)); }
+    *static_cast<volatile uint32_t *>(h) = 0u;
+    *host_ptr = h; *device_ptr = d;
+    return SAGE_OK;
+}
+SAGE_API int sage_host_word_free(void *host_ptr)
+{
+    if (host_ptr == nullptr) return SAGE_OK;
+    const hipError_t e = hipHostFree(host_ptr);
+    return e == hipSuccess ? SAGE_OK : fail(SAGE_ELAUNCH, "sage_host_word_free: %s", hipGetErrorString(e));
+}
+
+SAGE_API int sage_prepass_max_seqlen_stream(void *stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int cus = stream_cu_count(static_cast<hipStream_t>(stream), dev);
+    const int slabs = cus < sage::kPrepassMaxSlabs ? cus : sage::kPrepassMaxSlabs;
+    return slabs * sage::kStatsSlab;
+}
+
 SAGE_API int sage_prepass_failed_heads(const uint32_t *sync, int B, int H, void *stream)
 {
     if (!sync || B <= 0 || H <= 0) return fail(SAGE_EINVAL, "bad arguments");
@@ -334,7 +421,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
                     int B, int H, int L, int D,
                     int64_t k_sb, int64_t k_sh, int64_t k_sl, int64_t v_sb, int64_t v_sh, int64_t v_sl,
                     int64_t ko_sb, int64_t ko_sh, int64_t ko_sl,
-                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, void *stream)
+                    int k_blk, int qk_quant_gran, int k_style, float scale_max, int v_fp16, int dtype, uint32_t *host_flag, void *stream)
 {
     SAGE_REQUIRE(k || v, "nothing to do: both k and v are null");
     SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its sync buffer");
@@ -387,9 +474,64 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
     p.ko_sb = ko_sb; p.ko_sh = ko_sh; p.ko_sl = ko_sl;
     p.k_blk = k_blk; p.k_warp = k_blk; p.k_style = k_style; p.dtype = dtype; p.scale_max = scale_max; p.v_fp16 = v_fp16 ? 1 : 0;
     p.debug_fail = g_prepass_debug_fail;
+    p.host_flag = host_flag;
     // the per-head counters and give-up flags start from zero in every launch (a launch that gave up leaves them dirty); launch_prepass_kv
     // zeroes them with a small kernel of its own (a hipMemsetAsync node replayed wrongly inside a captured HIP graph on ROCm 7.0)
     return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv launch");
+}
+
+// packed (varlen) batches: K mean over all packed tokens + per-sequence INT8 K (Triton per-block rounding) + fp16 V tile image, one launch
+SAGE_API int sage_prepass_kv_varlen(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale, void *v_image,
+                                    float *ws, uint32_t *sync, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
+                                    const int32_t *slab_first, const int32_t *slab_seq, const int32_t *hdr,
+                                    int nseq, int total_tokens, int max_seqlen_k, int nslab_bound, int H, int D,
+                                    int64_t k_sl, int64_t k_sh, int64_t v_sl, int64_t v_sh, int64_t ko_sl, int64_t ko_sh,
+                                    int dtype, uint32_t *host_flag, void *stream)
+{
+    SAGE_REQUIRE(k && k_int8 && k_scale, "the varlen pre-pass needs k, k_int8 and k_scale");
+    SAGE_REQUIRE(!v || v_image, "V part needs v_image");
+    SAGE_REQUIRE(ws && sync, "the fused pre-pass needs its workspace and its sync buffer");
+    SAGE_REQUIRE(cu_seqlens_k && cu_k_scale && slab_first && slab_seq && hdr, "the varlen pre-pass needs the index arrays of sage_varlen_plan");
+    SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
+    SAGE_REQUIRE(nseq > 0 && H > 0 && total_tokens > 0 && max_seqlen_k > 0 && nslab_bound > 0, "empty batch");
+    SAGE_REQUIRE(H <= 65535, "head count too large for one launch (%d)", H);
+    SAGE_REQUIRE(nslab_bound >= (total_tokens + sage::kStatsSlab - 1) / sage::kStatsSlab, "nslab_bound (%d) is below ceil(total_tokens / %d)", nslab_bound, sage::kStatsSlab);
+    SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
+    {   // every slab of a head (all sequences) waits for the others when the K mean is asked for: they must be co-resident
+        int dev = 0;
+        SAGE_REQUIRE(hipGetDevice(&dev) == hipSuccess, "no current device");
+        const int cus = stream_cu_count(static_cast<hipStream_t>(stream), dev);
+        SAGE_REQUIRE(k_mean == nullptr || (nslab_bound <= sage::kPrepassMaxSlabs && nslab_bound <= cus),
+                     "up to %d slabs per head cannot wait for each other inside one launch (limit %d, %d compute units on this stream): use the "
+                     "sage_channel_mean / sage_quant_qk_int8_varlen / sage_prep_v_f16_varlen sequence", nslab_bound, sage::kPrepassMaxSlabs, cus);
+    }
+    const int64_t lpad = ((int64_t)max_seqlen_k + sage::kStatsSlab - 1) / sage::kStatsSlab * sage::kStatsSlab;
+    SAGE_REQUIRE(aligned16(k) && aligned16(k_int8) && (!v || (aligned16(v) && aligned16(v_image))), "k / k_int8 / v / v_image must be 16-byte aligned");
+    SAGE_REQUIRE(k_sl % 8 == 0 && k_sh % 8 == 0 && (!v || (v_sl % 8 == 0 && v_sh % 8 == 0)), "input strides must be multiples of 8 elements");
+    SAGE_REQUIRE(ko_sl % 16 == 0 && ko_sh % 16 == 0, "int8 output strides must be multiples of 16");
+    SAGE_REQUIRE(((lpad - 1) * k_sl + D) * 2 < (int64_t)1 << 32 && (lpad - 1) * ko_sl + D < (int64_t)1 << 32 &&
+                 (!v || ((lpad - 1) * v_sl + D) * 2 < (int64_t)1 << 32),
+                 "one sequence of one head (rounded up to whole 512-row slabs) spans 4 GiB or more: the kernel addresses it with 32-bit buffer offsets");
+    sage::PrepassParams p{};
+    p.parts = 1 | (v ? 2 : 0);
+    p.k = k; p.v = v; p.k_mean = k_mean; p.k_out = k_int8; p.k_scale = k_scale;
+    p.v_image = v_image; p.v_scale = nullptr; p.v_mean = nullptr; p.ws = ws; p.sync = sync;
+    p.B = 1; p.H = H; p.L = total_tokens; p.D = D; p.nslab = nslab_bound;
+    p.k_sb = 0; p.k_sh = k_sh; p.k_sl = k_sl; p.v_sb = 0; p.v_sh = v_sh; p.v_sl = v_sl;
+    p.ko_sb = 0; p.ko_sh = ko_sh; p.ko_sl = ko_sl;
+    p.k_blk = 64; p.k_warp = 64; p.k_gran = sage::GR_BLOCK; p.k_style = sage::QS_TRITON;      // quant_per_block_varlen.py:21-58
+    p.dtype = dtype; p.scale_max = 448.0f; p.v_fp16 = 1;
+    p.debug_fail = g_prepass_debug_fail;
+    p.host_flag = host_flag;
+    p.cu = cu_seqlens_k; p.cu_tiles = cu_k_scale; p.slab_seq = slab_seq; p.slab_first = slab_first; p.hdr = hdr;
+    return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv_varlen launch");
+}
+
+// test hook: `nwg` workgroups of 1024 threads that spin for `ms` milliseconds (two of them fill a compute unit's wave slots)
+SAGE_API int sage_debug_spin(int ms, int nwg, void *stream)
+{
+    SAGE_REQUIRE(ms > 0 && ms <= 10000 && nwg > 0 && nwg <= 4096, "sage_debug_spin: bad argument");
+    return check_launch(sage::launch_debug_spin(ms, nwg, static_cast<hipStream_t>(stream)), "sage_debug_spin launch");
 }
 
 SAGE_API int sage_prep_v_f16(const void *v, void *v_image, const float *v_mean, int B, int H, int L, int D,
@@ -450,6 +592,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                                     const float *q_scale, const float *k_scale,
                                     const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                                     const int32_t *cu_q_scale, const int32_t *cu_k_scale, const int32_t *seq_order,
+                                    const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                     int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
                                     int is_causal, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
@@ -457,7 +600,8 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
     return attn_common(false, true, q, k, v_image, o, nullptr, q_scale, k_scale, nullptr, nullptr,
                        cu_seqlens_q, cu_seqlens_k, cu_q_scale, cu_k_scale,
                        nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
-                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order);
+                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order,
+                       work_items, work_hdr, items_bound);
 }
 
 static int fused_q_common(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -522,6 +666,7 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
 // q in fp16 / bf16, quantised per 128-row block in the kernel prologue (dense: cu_q == nullptr; varlen: packed tensors, B = nseq)
 static int fused_qblock_common(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
                                const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_ks, const int32_t *seq_order,
+                               const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl,
@@ -544,6 +689,9 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.k_scale = k_scale;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = nullptr; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
+    SAGE_REQUIRE((work_items == nullptr) == (work_hdr == nullptr) && (work_items == nullptr || (varlen && items_bound > 0)),
+                 "the work list comes as (work_items, work_hdr, items_bound > 0), varlen only");
+    p.work_items = work_items; p.work_hdr = work_hdr; p.items_bound = items_bound;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
     p.Lq = Lq; p.Lk = Lk;
     p.nqblk = (Lq + sage::BLKQ - 1) / sage::BLKQ;
@@ -566,19 +714,20 @@ SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                            int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
 {
-    return fused_qblock_common(q, k, v_image, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, B, Hq, Hkv, Lq, Lk, D,
+    return fused_qblock_common(q, k, v_image, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Hq, Hkv, Lq, Lk, D,
                                q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, q_dtype, out_dtype, stream);
 }
 
 SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
                                                   const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
-                                                  const int32_t *seq_order, int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
+                                                  const int32_t *seq_order, const int32_t *work_items, const int32_t *work_hdr, int items_bound,
+                                                  int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                                   int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
                                                   int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
 {
     SAGE_REQUIRE(cu_seqlens_q != nullptr, "varlen needs cu_seqlens_q");
     return fused_qblock_common(q, k, v_image, o, nullptr, k_scale, cu_seqlens_q, cu_seqlens_k, cu_k_scale, seq_order,
-                               nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
+                               work_items, work_hdr, items_bound, nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
                                is_causal, q_premul, q_dtype, out_dtype, stream);
 }
 

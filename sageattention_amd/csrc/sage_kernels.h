@@ -24,7 +24,10 @@ struct AttnParams {
     const int32_t *cu_k;
     const int32_t *cu_qs;     // prefix sums of ceil(Lq_i/128)
     const int32_t *cu_ks;     // prefix sums of ceil(Lk_i/64)
-    const int32_t *seq_order; // varlen, nullable: permutation of sequence indices in processing order
+    const int32_t *seq_order; // varlen, nullable: permutation of sequence indices in processing order (legacy unit order, no work list)
+    const int32_t *work_items;// varlen, nullable: the device-built work list of sage_varlen_plan ((sequence, query block), heaviest first)
+    const int32_t *work_hdr;  // with work_items: {nitems, group, fold, left, ...} (kVarlenHdrWords)
+    int items_bound;          // with work_items: host-known upper bound of nitems (sizes the grid)
     int B, Hq, Hkv, group;    // group = Hq / Hkv
     int Lq, Lk;               // dense lengths; varlen: max lengths (grid sizing only)
     int nqblk;                // ceil(max Lq / 128)
@@ -54,13 +57,6 @@ hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, i
 // form, per-block k scales; dense or varlen (p.cu_q)
 hipError_t launch_attn_fused_qblock(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream);
 
-// FP8 PV, dense, unmasked, D = 128 in the one-wave-per-SIMD form (sage_attn64.hip): 256 query rows per workgroup, 64 per wave.
-// qf: 0 = INT8 q + q_scale (any granularity), 1 / 2 = fp16 / bf16 q quantised in the prologue (per-thread groups)
-hipError_t launch_attn64(const AttnParams &p, int head_dim, bool causal, bool kthread, int qf, hipStream_t stream);
-// route of the FP8 D = 128 dense calls: -1 auto (by shape), 0 the 128-row kernel (sage_attn.hip), 1 the 256-row kernel
-// (sage_attn64.hip) wherever it is eligible.  Initialised from the environment variable SAGE_ATTN64; tests and benchmarks set it.
-int attn64_mode();
-void set_attn64_mode(int mode);
 // causal dense work order of the 128-row kernels: -1 grouped / folded by grid size, 0 head-major, n groups of n heads (SAGE_ORDER_GROUP)
 int work_order();
 void set_work_order_mode(int group);
@@ -87,10 +83,22 @@ struct QuantParams {
     float pre_scale;
 };
 hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream);
-// packed batches: prefix sums of the per-sequence block counts and the longest-first processing order, one launch (nseq <= kVarlenPlanMaxSeq)
+// packed batches: every index array of a varlen call from one launch (sage_varlen_plan.hip), nseq <= kVarlenPlanMaxSeq
 constexpr int kVarlenPlanMaxSeq = 1024;
-hipError_t launch_varlen_plan(const int32_t *cu_q, const int32_t *cu_k, int nseq, int blkq, int blkk,
-                              int32_t *cu_qs, int32_t *cu_ks, int32_t *order, hipStream_t stream);
+constexpr int kVarlenHdrWords = 8;       // hdr: nitems, group, fold, left, nslab (K / V pre-pass slabs), max Lk, sum Lk, 0
+struct VarlenPlanParams {
+    const int32_t *cu_q, *cu_k;          // [nseq + 1]
+    int nseq, blkq, blkk;
+    int causal, Hq, Hkv, head_dim, pv_fp8;   // for the launch plan (hdr) only
+    int32_t *cu_qs;                      // nullable [nseq + 1]
+    int32_t *cu_ks;                      // [nseq + 1]
+    int32_t *order;                      // nullable [nseq]
+    int32_t *items;                      // nullable [2 * nitems]: (sequence, query block), heaviest first
+    int32_t *slab_first;                 // nullable [nseq + 1]: prefix sums of ceil(Lk_i / 512)
+    int32_t *slab_seq;                   // nullable [nslab]: slab -> sequence
+    int32_t *hdr;                        // nullable [kVarlenHdrWords]
+};
+hipError_t launch_varlen_plan(const VarlenPlanParams &p, hipStream_t stream);
 
 // ---- per-channel statistics over the sequence (K mean, V amax / mean) -----------------------------
 #ifndef SAGE_STATS_SLAB
@@ -105,6 +113,8 @@ struct StatsParams {
     int B, H, L, D, nslab;
     long x_sb, x_sh, x_sl;
     int dtype;
+    // packed batches (nullable, together): slabs per sequence as sage_varlen_plan lays them out; nslab = host-known bound, L = sum L
+    const int32_t *cu, *slab_first, *slab_seq, *hdr;
 };
 hipError_t launch_stats(const StatsParams &p, hipStream_t stream);
 
@@ -155,8 +165,18 @@ struct PrepassParams {
     int dtype;
     float scale_max;          // 448 for e4m3
     int debug_fail;           // test hook (sage_debug_prepass_fail): wait for one slab more than exists and give up after 2^10 polls
+    unsigned *host_flag;      // nullable: device-visible pinned HOST word that a workgroup which gives up sets to 1 (system-scope store), so
+                              // the caller can learn of a poisoned launch at its next call without a synchronisation
+    // packed (varlen) batches: k / v are [sum L, H, D]; a slab is 512 tokens of ONE sequence, the head barrier and the K mean span all
+    // sequences (core.py:432-434).  B = 1, L = sum L (the mean's divisor), nslab = host-known bound of the slab count (grid, workspace)
+    const int32_t *cu;        // null => dense.  cu_seqlens_k [nseq + 1]
+    const int32_t *cu_tiles;  // prefix sums of ceil(L_i / 64): k scale block / V tile index of a sequence's first block
+    const int32_t *slab_seq;  // slab -> sequence
+    const int32_t *slab_first;// prefix sums of ceil(L_i / 512)
+    const int32_t *hdr;       // sage_varlen_plan's header: hdr[4] = number of slabs that exist
 };
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t stream);
+hipError_t launch_debug_spin(int ms, int nwg, hipStream_t stream);
 
 // ---- LSE merge of partial attention states (sequence-parallel callers) -----------------------------
 struct MergeParams {

@@ -98,7 +98,10 @@ struct PrepassLds {
 // The K half and the V half are two instantiations of this body under one workgroup-uniform branch of the kernel.  Written as
 // one body with `is_v` selects they needed > 128 VGPRs and spilled (every reload is a memory round trip behind
 // `s_waitcnt vmcnt(0)`: the passes ran 2.5x slower); as two disjoint regions they take 115 / 127 and nothing spills.
-template <int D, int DT, bool IS_V>
+// VARLEN: k / v are packed [sum L, H, D] (sageattn_varlen, core.py:431-444): blockIdx.x is the slab's index among ALL slabs of the head
+// (sage_varlen_plan: 512-token slabs per sequence, so the 64-key scale blocks and V tiles of a sequence never straddle a slab); the
+// statistics, the barrier and the K mean span every sequence (`k.mean(dim=0)` over all packed tokens), the quantisation is per sequence.
+template <int D, int DT, bool IS_V, bool VARLEN>
 __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<D> &lds, const int b)
 {
 
@@ -122,12 +125,23 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     constexpr int is_v = IS_V ? 1 : 0;
 
     const int tid = threadIdx.x;
-    const int slab = blockIdx.x, h = blockIdx.y;
-    const int L = p.L;
+    const int gslab = blockIdx.x, h = blockIdx.y;          // gslab: index among the head's slabs (the statistics / barrier index)
+    int slab = gslab, L = p.L, nslab = p.nslab;            // slab: index inside the sequence; L: rows of the sequence; nslab: slabs of the head
+    long tok0 = 0, tile0 = 0;                              // VARLEN: first packed token / first 64-key block of the sequence
+    if constexpr (VARLEN) {
+        typedef const __attribute__((address_space(4))) int *cint_p;          // wave-uniform: scalar loads
+        nslab = ((cint_p)p.hdr)[4];
+        if (gslab >= nslab) return;                        // the grid is sized by a host-known bound (workgroup-uniform exit)
+        const int seq = ((cint_p)p.slab_seq)[gslab];
+        slab = gslab - ((cint_p)p.slab_first)[seq];
+        tok0 = ((cint_p)p.cu)[seq];
+        L = ((cint_p)p.cu)[seq + 1] - (int)tok0;
+        tile0 = ((cint_p)p.cu_tiles)[seq];
+    }
     const long bh = (long)b * p.H + h;
-    const uint16_t *x = is_v ? reinterpret_cast<const uint16_t *>(p.v) + (long)b * p.v_sb + (long)h * p.v_sh
-                             : reinterpret_cast<const uint16_t *>(p.k) + (long)b * p.k_sb + (long)h * p.k_sh;
     const long x_sl = is_v ? p.v_sl : p.k_sl;
+    const uint16_t *x = (is_v ? reinterpret_cast<const uint16_t *>(p.v) + (long)b * p.v_sb + (long)h * p.v_sh
+                              : reinterpret_cast<const uint16_t *>(p.k) + (long)b * p.k_sb + (long)h * p.k_sh) + tok0 * x_sl;
     const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
     const int row0 = slab * kStatsSlab;
     const int end = min(L, row0 + kStatsSlab);
@@ -204,7 +218,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             float a = -INFINITY, c = INFINITY, s = 0.0f;
 #pragma unroll
             for (int r = 0; r < RPI; r++) { a = fmaxf(a, red[0][r][tid]); c = fminf(c, red[1][r][tid]); s += red[2][r][tid]; }
-            float *mine = ws + (long)slab * 3 * D;
+            float *mine = ws + (long)gslab * 3 * D;
             __hip_atomic_store(mine + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(mine + D + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(mine + 2 * D + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -212,7 +226,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         SAGE_STAMP();                              // 2: slab statistics published
         // ---- 2. per-head barrier over the slabs, then the reduction in slab order (as stats_final_kernel) -------------
         unsigned *cnt = p.sync + ((long)is_v * p.B * p.H + bh) * kPrepassSyncStride;   // one 128-B line per head
-        if (p.nslab > 1 && !(SAGE_PP_ABL & 1)) {
+        if (nslab > 1 && !(SAGE_PP_ABL & 1)) {
             // Everything that crosses workgroups here is an agent-scope atomic access (write-through / cache-bypassing,
             // coherent across the XCDs by itself), so the ordering needs no L2 write-back or invalidate -- a fence at
             // agent scope would put `buffer_wbl2` / `buffer_inv` into every spin iteration of every waiting workgroup
@@ -224,12 +238,16 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 __hip_atomic_fetch_add(cnt, 1u, SAGE_PP_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // bounded (about a second): if the forward-progress assumption above were ever violated the launch would
                 // finish with NaN-poisoned outputs and a flag in the head's sync line instead of hanging the device
-                const unsigned want = (unsigned)p.nslab + (p.debug_fail ? 1u : 0u);
+                const unsigned want = (unsigned)nslab + (p.debug_fail ? 1u : 0u);
                 const unsigned bound = p.debug_fail ? (1u << 10) : (1u << 20);
                 unsigned polls = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++polls > bound) { __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (++polls > bound) {
+                        __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.host_flag != nullptr) __hip_atomic_store(p.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
                 // a workgroup that arrives after another one gave up finds the count complete -- and the flag set
                 lds.failed = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -243,11 +261,11 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             // not one per slab: with the loads issued one by one this loop alone cost ~2 us x nslab per workgroup)
             float a = -INFINITY, c = INFINITY, s = 0.0f;
             constexpr int NB = (D == 128) ? 16 : 8;       // slabs per batch of loads (D = 64: 8 keeps the kernel at 3 workgroups per CU)
-            for (int i0 = 0; i0 < p.nslab; i0 += NB) {
+            for (int i0 = 0; i0 < nslab; i0 += NB) {
                 float va[NB], vc[NB], vs[NB];
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
-                    const float *wi = ws + (long)min(i0 + u, p.nslab - 1) * 3 * D;
+                    const float *wi = ws + (long)min(i0 + u, nslab - 1) * 3 * D;
                     if constexpr (IS_V) {
                         va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         vc[u] = __hip_atomic_load(wi + D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -256,16 +274,16 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 }
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
-                    if (i0 + u < p.nslab) {
+                    if (i0 + u < nslab) {
                         if constexpr (IS_V) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); }
                         s += vs[u];
                     }
                 }
             }
             if constexpr (!IS_V) {
-                const uint16_t m = st16<DT>(s / (float)L);           // k.mean(dim=seq) in the input dtype, one rounding
+                const uint16_t m = st16<DT>(s / (float)(VARLEN ? p.L : L));      // k.mean(dim=seq) in the input dtype, one rounding (VARLEN: over all packed tokens)
                 kmean[tid] = m;
-                if (slab == 0) reinterpret_cast<uint16_t *>(p.k_mean)[bh * D + tid] = m;
+                if (gslab == 0) reinterpret_cast<uint16_t *>(p.k_mean)[bh * D + tid] = m;
             } else {
                 // per-channel scale (and mean for smooth_v): the rules of prep_v_kernel (fused.cu:335-395)
                 const bool smooth = p.v_mean != nullptr;
@@ -275,7 +293,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 const float am = fmaxf(fabsf(a - mean), fabsf(c - mean));
                 ch_mean[tid] = mean;
                 ch_recp[tid] = am > 0.0f ? p.scale_max / am : 0.0f;
-                if (slab == 0) {
+                if (gslab == 0) {
                     p.v_scale[bh * D + tid] = failed ? __uint_as_float(0x7fc00000u) : am / p.scale_max;
                     if (smooth) p.v_mean[bh * D + tid] = mean;
                 }
@@ -283,9 +301,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         }
         __syncthreads();
         SAGE_STAMP();                              // 4: head statistics reduced
-        if (p.nslab > 1 && tid == 0 && !(SAGE_PP_ABL & 1)) {          // the last slab to leave re-arms the head's counters
+        if (nslab > 1 && tid == 0 && !(SAGE_PP_ABL & 1)) {          // the last slab to leave re-arms the head's counters
             const unsigned left = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left == (unsigned)p.nslab - 1) {
+            if (left == (unsigned)nslab - 1) {
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -329,7 +347,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         const int nblk_total = (L + blk - 1) >> bsh;
         // buffer stores: rows past the end of the head are dropped by the range check
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-            p.k_out + (long)b * p.ko_sb + (long)h * p.ko_sh, 0, (unsigned)((long)(L - 1) * p.ko_sl + D), 0x00020000);
+            p.k_out + (long)b * p.ko_sb + (long)h * p.ko_sh + tok0 * p.ko_sl, 0, (unsigned)((long)(L - 1) * p.ko_sl + D), 0x00020000);
         const unsigned ooff = (unsigned)((row0 + r0) * (int)p.ko_sl + c4), ostep = (unsigned)(RPI * (int)p.ko_sl);
 
         // STYLE: 0 the CUDA quantiser (fp32 difference, round-to-nearest-even, fused.cu:131-172), 1 Triton rounding with
@@ -412,7 +430,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 const float sc = quant_scale(am, p.k_style);
                 gsc[kb][g] = sc;
                 gy[kb][g] = (STYLE == 0) ? 127.0f / am : quant_recip(sc);       // fused.cu:164
-                if (gb < nblk_total) p.k_scale[(bh * nblk_total + gb) * ngroups + g] = failed ? __uint_as_float(0x7fc00000u) : sc;
+                float *ksc_out = VARLEN ? p.k_scale + (tile0 + gb) * p.H + h                   // [sum nblk, H] (quant_per_block_varlen.py:75-76)
+                                        : p.k_scale + (bh * nblk_total + gb) * ngroups + g;
+                if (gb < nblk_total) *ksc_out = failed ? __uint_as_float(0x7fc00000u) : sc;
             }
             __syncthreads();
             unsigned orun = ooff;
@@ -457,7 +477,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             }
         };
         if (p.v_fp16 == 0) {
-            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 64);
+            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 64);      // (dense only: the varlen call has no FP8 image)
 #pragma unroll
             for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
                 if (row0 + s * 2 * BLKK < L) {                  // workgroup-uniform
@@ -497,7 +517,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         } else {
             // FP16-PV entry points: `v.to(float16)` (core.py:297-298,613) as the fp16 tile image of prep_v_kernel -- no
             // statistics, no barrier: load, transpose through LDS, store
-            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + bh * (long)ntiles * (D * 128);
+            // dense: [B, H, ntiles, D, 64]; VARLEN: [sum ntiles, H, D, 64] (tile-major, the layout of prep_v_kernel's packed form)
+            const long img_t = VARLEN ? (long)p.H * (D * 128) : (long)(D * 128);
+            unsigned char *img = reinterpret_cast<unsigned char *>(p.v_image) + (VARLEN ? (tile0 * p.H + h) * (long)(D * 128) : bh * (long)ntiles * (D * 128));
 #pragma unroll
             for (int s = 0; s < kStatsSlab / (2 * BLKK); s++) {
                 if (row0 + s * 2 * BLKK < L) {
@@ -524,8 +546,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                             }
                             pk[w] = word;
                         }
-                        if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 128) + d * 128 + pc * 16));
-                        else *reinterpret_cast<v4u *>(img + (long)t * (D * 128) + d * 128 + pc * 16) = pk;
+                        if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * img_t + d * 128 + pc * 16));
+                        else *reinterpret_cast<v4u *>(img + (long)t * img_t + d * 128 + pc * 16) = pk;
                     }
                     __syncthreads();
                 }
@@ -541,7 +563,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 #endif
 }
 
-template <int D, int DT>
+template <int D, int DT, bool VARLEN>
 #ifndef SAGE_PP_WAVES      // waves per SIMD the allocator must allow (4 = two 512-thread workgroups per CU)
 #define SAGE_PP_WAVES 4
 #endif
@@ -553,14 +575,26 @@ prepass_kv_kernel(const PrepassParams p)
     // measured the same at C3 and 15 % slower at B=16 H=32 N=1024)
     const int is_v = (p.parts == 3) ? (int)(blockIdx.z & 1) : (p.parts == 2);
     const int b = (p.parts == 3) ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
-    if (is_v) prepass_body<D, DT, true>(p, lds, b);
-    else prepass_body<D, DT, false>(p, lds, b);
+    if (is_v) prepass_body<D, DT, true, VARLEN>(p, lds, b);
+    else prepass_body<D, DT, false, VARLEN>(p, lds, b);
 }
 
 __global__ void __launch_bounds__(256) prepass_zero_sync_kernel(unsigned *sync, int words)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < words) sync[i] = 0u;
+}
+
+__global__ void __launch_bounds__(1024) debug_spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();                // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+hipError_t launch_debug_spin(int ms, int nwg, hipStream_t s)
+{
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(nwg), dim3(1024), 0, s, (long long)ms * 100000LL);
+    return hipGetLastError();
 }
 
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t s)
@@ -571,7 +605,8 @@ hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t s)
         hipLaunchKernelGGL(prepass_zero_sync_kernel, dim3((words + 255) / 256), dim3(256), 0, s, p.sync, words);
     }
     dim3 grid(p.nslab, p.H, p.B * (p.parts == 3 ? 2 : 1));
-#define SAGE_PP(D_, T_) hipLaunchKernelGGL((prepass_kv_kernel<D_, T_>), grid, dim3(kPrepassThreads), 0, s, p)
+#define SAGE_PP(D_, T_) do { if (p.cu != nullptr) hipLaunchKernelGGL((prepass_kv_kernel<D_, T_, true>), grid, dim3(kPrepassThreads), 0, s, p); \
+                             else hipLaunchKernelGGL((prepass_kv_kernel<D_, T_, false>), grid, dim3(kPrepassThreads), 0, s, p); } while (0)
     if (p.D == 128) { if (p.dtype == DT_F16) SAGE_PP(128, DT_F16); else SAGE_PP(128, DT_BF16); }
     else if (p.D == 64) { if (p.dtype == DT_F16) SAGE_PP(64, DT_F16); else SAGE_PP(64, DT_BF16); }
     else return hipErrorInvalidValue;

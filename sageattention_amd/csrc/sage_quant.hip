@@ -151,50 +151,4 @@ hipError_t launch_quant_int8(const QuantParams &p, hipStream_t stream)
     return hipErrorInvalidValue;
 }
 
-// ---- varlen plan: the small index arrays a packed-batch call needs, in ONE launch ------------------------------------------------
-// cu_qs / cu_ks = exclusive prefix sums of ceil(L_i / blkq), ceil(L_i / blkk) (the reference builds them with torch ops,
-// quant_per_block_varlen.py:68-73) and `order` = the sequences by descending query length (the attention launcher's processing order).
-// One workgroup: nseq is small (<= kVarlenPlanMaxSeq); Hillis-Steele scans in LDS, rank by counting.
-__global__ void __launch_bounds__(1024) varlen_plan_kernel(const int32_t *cu_q, const int32_t *cu_k, int nseq, int blkq, int blkk,
-                                                          int32_t *cu_qs, int32_t *cu_ks, int32_t *order)
-{
-    __shared__ int sq[2][kVarlenPlanMaxSeq], sk[2][kVarlenPlanMaxSeq], len[kVarlenPlanMaxSeq];
-    const int i = threadIdx.x;
-    int lq = 0;
-    if (i < nseq) {
-        lq = cu_q[i + 1] - cu_q[i];
-        const int lk = cu_k[i + 1] - cu_k[i];
-        sq[0][i] = (lq + blkq - 1) / blkq;
-        sk[0][i] = (lk + blkk - 1) / blkk;
-        len[i] = lq;
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int d = 1; d < nseq; d <<= 1) {                 // inclusive scans
-        if (i < nseq) {
-            sq[cur ^ 1][i] = sq[cur][i] + (i >= d ? sq[cur][i - d] : 0);
-            sk[cur ^ 1][i] = sk[cur][i] + (i >= d ? sk[cur][i - d] : 0);
-        }
-        cur ^= 1;
-        __syncthreads();
-    }
-    if (i < nseq) {
-        if (cu_qs != nullptr) cu_qs[i + 1] = sq[cur][i];
-        cu_ks[i + 1] = sk[cur][i];
-        int rank = 0;                                    // longer sequences first; ties by index (a total order: every slot written once)
-        for (int j = 0; j < nseq; j++) rank += (len[j] > lq || (len[j] == lq && j < i)) ? 1 : 0;
-        order[rank] = i;
-    }
-    if (i == 0) { if (cu_qs != nullptr) cu_qs[0] = 0; cu_ks[0] = 0; }
-}
-
-hipError_t launch_varlen_plan(const int32_t *cu_q, const int32_t *cu_k, int nseq, int blkq, int blkk,
-                              int32_t *cu_qs, int32_t *cu_ks, int32_t *order, hipStream_t stream)
-{
-    if (nseq <= 0) return hipSuccess;
-    if (nseq > kVarlenPlanMaxSeq) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(varlen_plan_kernel, dim3(1), dim3(1024), 0, stream, cu_q, cu_k, nseq, blkq, blkk, cu_qs, cu_ks, order);
-    return hipGetLastError();
-}
-
 }  // namespace sage

@@ -27,11 +27,19 @@ stats_partial_kernel(const StatsParams p)
     float mx[8], mn[8], sm[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; sm[j] = 0.0f; }
-    const int end = min(p.L, slab * kStatsSlab + kStatsSlab);
+    // rows [start, end) of the slab.  Packed batches (p.slab_seq): a slab is 512 tokens of ONE sequence -- the partition of the one-launch
+    // varlen pre-pass (sage_prepass.hip), so that both routes sum in the same order and give the same mean bit for bit
+    int start = slab * kStatsSlab, end = min(p.L, slab * kStatsSlab + kStatsSlab);
+    if (p.slab_seq != nullptr) {
+        if (slab >= p.hdr[4]) return;
+        const int seq = p.slab_seq[slab];
+        start = p.cu[seq] + (slab - p.slab_first[seq]) * kStatsSlab;
+        end = min(p.cu[seq + 1], start + kStatsSlab);
+    }
     // eight independent 16-byte loads in flight per thread: with one load per thread the 1024-workgroup grid keeps
     // only ~4 MB in flight chip-wide, half of what a cold HBM read stream needs; rows are still accumulated in order
     constexpr int UNR = 8;
-    for (int r = slab * kStatsSlab + r0; r < end; r += UNR * RPI) {
+    for (int r = start + r0; r < end; r += UNR * RPI) {
         v4u raw[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
@@ -69,20 +77,21 @@ __global__ void stats_final_kernel(const StatsParams p)
 {
     const int d = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
     const float *ws = p.ws + ((long)b * p.H + h) * p.nslab * 3 * D;
+    const int nslab = p.slab_seq != nullptr ? p.hdr[4] : p.nslab;      // packed batches: p.nslab is the host-known bound (workspace stride)
     float a = -INFINITY, c = INFINITY, s = 0.0f;
     // slabs in index order (the summation order every route shares); sixteen slabs' loads are in flight together -- issued one by one
     // this loop is a chain of L2 round trips: 19 us for the 66 slabs of a C4 call
     constexpr int NB = 16;
-    for (int i0 = 0; i0 < p.nslab; i0 += NB) {
+    for (int i0 = 0; i0 < nslab; i0 += NB) {
         float va[NB], vc[NB], vs[NB];
 #pragma unroll
         for (int u = 0; u < NB; u++) {
-            const float *wi = ws + (long)(i0 + u < p.nslab ? i0 + u : p.nslab - 1) * 3 * D;
+            const float *wi = ws + (long)(i0 + u < nslab ? i0 + u : nslab - 1) * 3 * D;
             va[u] = wi[d]; vc[u] = wi[D + d]; vs[u] = wi[2 * D + d];
         }
 #pragma unroll
         for (int u = 0; u < NB; u++)
-            if (i0 + u < p.nslab) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); s += vs[u]; }
+            if (i0 + u < nslab) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); s += vs[u]; }
     }
     if (p.stats != nullptr) {
         float *st = p.stats + ((long)b * p.H + h) * 3 * D;

@@ -15,7 +15,7 @@
 // the i-th longest and the i-th shortest block.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SAGE_HD __host__ __device__ __forceinline__
 #else
 #define SAGE_HD inline
@@ -68,7 +68,7 @@ SAGE_HD bool work_item(const WorkOrder &w, int bid, int nwg, int nheads, int nqb
 //            (C3, 2 MB per head: FETCH_SIZE 105 k KiB at G=1, 148 k at G=2, 284 k at G=4, 587 k at G=8 for 7.4 / 8.9 / 9.3 % less
 //            time than head-major), so up to twice the balance size is taken only while the group fits the L2
 // (profiles/r3_run_j_work_order_ab.txt, r3_run_k_order_traffic.txt).
-inline int plan_work_order(WorkOrder &w, int nheads, int nqblk, long kv_len, int head_dim, bool pv_fp8, int forced)
+SAGE_HD int plan_work_order(WorkOrder &w, int nheads, int nqblk, long kv_len, int head_dim, bool pv_fp8, int forced)
 {
     const int hpx = nheads / 8, left = nheads % 8;
     const int wg_per_cu = head_dim == 64 ? 3 : 2;                 // SAGE_MIN_WAVES of the 128-row kernels
@@ -86,6 +86,73 @@ inline int plan_work_order(WorkOrder &w, int nheads, int nqblk, long kv_len, int
     const bool one_sorted_list = (left == 0 && grp >= hpx) || hpx == 0;
     w.fold = (wg_per_cu == 2 && cnt > 32 && cnt <= 64 && one_sorted_list) ? 1 : 0;
     return 8 * cnt;
+}
+
+// ---- packed (varlen) batches ---------------------------------------------------------------------------------------------------
+// The query blocks of ALL sequences form one item list per query head, sorted by descending weight (64-key tiles the block visits);
+// the launch then IS a dense launch over nheads = Hq heads of `nitems` "query blocks" each: the same work_item() deals the list to the
+// XCDs, so a kv-head's K/V of every sequence streams through one L2 and the heaviest blocks are dispatched first.  The list is built on
+// the device (varlen_plan_kernel, sage_quant.hip) from the functions below; sage_debug_varlen_items runs the same functions on the host.
+// The reference sizes its grid by max_seqlen_q for every sequence and lets the blocks past a sequence's end exit
+// (triton/attn_qk_int8_block_varlen.py:22-30,98-121).
+
+// 64-key tiles query block j (128 rows) of a sequence with lq queries and lk keys visits (top-left causal mask: key <= query)
+SAGE_HD int varlen_item_weight(int lk, int j, bool causal)
+{
+    const int ntk = (lk + 63) >> 6;
+    if (!causal) return ntk;
+    const int lim = 2 * j + 2;
+    return lim < ntk ? lim : ntk;
+}
+
+// number of query blocks j in [0, nq) of that sequence whose weight is > w
+SAGE_HD int varlen_count_heavier(int nq, int lk, int w, bool causal)
+{
+    const int ntk = (lk + 63) >> 6;
+    if (ntk <= w || nq <= 0) return 0;
+    if (!causal) return nq;
+    const int first = w < 0 ? 0 : (w >> 1);            // 2 j + 2 > w  <=>  j >= floor(w / 2)
+    return first < nq ? nq - first : 0;
+}
+
+// rank of item (sequence s, query block j) in the list sorted by (weight descending, sequence index ascending, query block descending):
+// a total order, so every rank in [0, nitems) is taken exactly once.  lq / lk: the nseq sequence lengths.
+SAGE_HD int varlen_item_rank(const int *lq, const int *lk, int nseq, int s, int j, bool causal)
+{
+    const int w = varlen_item_weight(lk[s], j, causal);
+    int rank = 0;
+    for (int t = 0; t < nseq; t++) {
+        const int nq = (lq[t] + 127) >> 7;
+        const int gt = varlen_count_heavier(nq, lk[t], w, causal);
+        rank += gt;
+        if (t < s) rank += varlen_count_heavier(nq, lk[t], w - 1, causal) - gt;           // equal weight, earlier sequence
+    }
+    // equal weight, same sequence, later query block (weights do not decrease with j, so these are j + 1 .. last block of weight w)
+    const int nq_s = (lq[s] + 127) >> 7;
+    const int ge_w = varlen_count_heavier(nq_s, lk[s], w - 1, causal);                      // blocks of weight >= w: the last ge_w blocks
+    const int gt_w = varlen_count_heavier(nq_s, lk[s], w, causal);
+    rank += (nq_s - gt_w) - 1 - j;                                                         // blocks j' with j < j' < nq_s - gt_w
+    (void)ge_w;
+    return rank;
+}
+
+// the launch plan over that list: group / fold / left as for a dense causal launch of `nheads` = Hq heads with `nitems` blocks each,
+// the group rounded up to whole GQA groups (their query heads share one K/V stream at no L2 cost); returns the grid size
+SAGE_HD int plan_varlen_order(WorkOrder &w, int nheads, int gqa_group, int nitems, long max_kv_len, int head_dim, bool pv_fp8)
+{
+    if (nitems <= 0) { w.group = 1; w.fold = 0; w.left = nheads & 7; return 0; }
+    const int grid = plan_work_order(w, nheads, nitems, max_kv_len, head_dim, pv_fp8, -1);
+    const int hpx = nheads >> 3;
+    if (gqa_group > 1 && hpx > 0) {
+        int g = ((w.group + gqa_group - 1) / gqa_group) * gqa_group;
+        g = g > hpx ? hpx : g;
+        if (g != w.group) w.fold = 0;              // the fold needs one sorted list per XCD (plan_work_order decided it for its own group)
+        w.group = g;
+        const int cnt = w.left * ((nitems + 7) / 8) + hpx * nitems;
+        const bool one_sorted_list = (w.left == 0 && w.group >= hpx);
+        w.fold = ((head_dim == 64 ? 3 : 2) == 2 && cnt > 32 && cnt <= 64 && one_sorted_list) ? 1 : 0;
+    }
+    return grid;
 }
 
 }  // namespace sage

@@ -14,7 +14,10 @@ returned as the gfx950 *tile image* ``[B, H, ceil(L/64), D, 64]`` documented in
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes
+import os
+import warnings
+from typing import NamedTuple, Optional, Tuple
 
 import torch
 
@@ -139,11 +142,27 @@ def _cu_blocks(cu: torch.Tensor, blk: int) -> torch.Tensor:
     return torch.nn.functional.pad(torch.cumsum((lens + blk - 1) // blk, dim=0), (1, 0), value=0).to(torch.int32)
 
 
+class VarlenPlan(NamedTuple):
+    """Index arrays of one packed-batch call (``sage_varlen_plan``), all on the device, none read by the host."""
+    cu_qs: Optional[torch.Tensor]      # [nseq + 1] prefix sums of ceil(Lq_i / 128) (only when asked for)
+    cu_ks: torch.Tensor                # [nseq + 1] prefix sums of ceil(Lk_i / 64): k scale blocks and V tiles
+    order: torch.Tensor                # [nseq] sequences by descending query length (launches without a work list)
+    items: Optional[torch.Tensor]      # [items_bound, 2] (sequence, query block), heaviest first -- the attention launch's work list
+    hdr: Optional[torch.Tensor]        # [8] number of items, launch plan (group, fold, left), number of slabs, max Lk, sum Lk
+    slab_first: Optional[torch.Tensor]  # [nseq + 1] prefix sums of ceil(Lk_i / 512)
+    slab_seq: Optional[torch.Tensor]   # [slab_bound] slab -> sequence (K / V pre-pass)
+    items_bound: int                   # host-known bound of the item count: ceil(sum Lq / 128) + nseq
+    slab_bound: int                    # host-known bound of the slab count: ceil(sum Lk / 512) + nseq
+
+
 @_eager
-def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: int = 128, BLKK: int = 64, want_q_blocks: bool = False):
-    """The index arrays of a packed-batch call in one launch (``sage_varlen_plan``): ``(cu_qs | None, cu_ks, order)`` -- prefix sums of
-    the per-sequence block counts (the reference's torch ops, quant_per_block_varlen.py:68-73) and the sequences by descending query
-    length.  ``cu_seqlens_*`` int32, contiguous; at most ``sage_varlen_plan_max_seqs()`` sequences (``None`` otherwise)."""
+def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: int = 128, BLKK: int = 64, want_q_blocks: bool = False,
+                total_q: Optional[int] = None, total_k: Optional[int] = None, is_causal: bool = False, Hq: int = 1, Hkv: int = 1,
+                head_dim: int = 128, pv_fp8: bool = False) -> Optional[VarlenPlan]:
+    """Every index array of a packed-batch call in one launch (``sage_varlen_plan``): the block-count prefix sums (the reference's
+    torch ops, quant_per_block_varlen.py:68-73), and -- when the packed token counts ``total_q`` / ``total_k`` (``q.shape[0]``,
+    ``k.shape[0]``: known on the host) are given -- the attention launch's work list with its plan and the slab map of the one-launch
+    K / V pre-pass.  ``cu_seqlens_*`` int32, contiguous; at most ``sage_varlen_plan_max_seqs()`` sequences (``None`` otherwise)."""
     nseq = cu_seqlens_q.shape[0] - 1
     lib = _cabi.load()
     if nseq < 1 or nseq > lib.sage_varlen_plan_max_seqs() or cu_seqlens_q.dtype != torch.int32 or cu_seqlens_k.dtype != torch.int32:
@@ -152,51 +171,72 @@ def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: in
     cu_qs = torch.empty((nseq + 1,), dtype=torch.int32, device=dev) if want_q_blocks else None
     cu_ks = torch.empty((nseq + 1,), dtype=torch.int32, device=dev)
     order = torch.empty((nseq,), dtype=torch.int32, device=dev)
-    rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, BLKQ, BLKK, _p(cu_qs), _p(cu_ks), _p(order), _stream(cu_seqlens_q))
+    items = hdr = slab_first = slab_seq = None
+    items_bound = slab_bound = 0
+    work = total_q is not None and total_k is not None and BLKQ == 128 and BLKK == 64
+    if work:
+        items_bound = (int(total_q) + 127) // 128 + nseq
+        slab_bound = (int(total_k) + 511) // 512 + nseq
+        items = torch.empty((items_bound, 2), dtype=torch.int32, device=dev)
+        hdr = torch.empty((8,), dtype=torch.int32, device=dev)
+        slab_first = torch.empty((nseq + 1,), dtype=torch.int32, device=dev)
+        slab_seq = torch.empty((slab_bound,), dtype=torch.int32, device=dev)
+    rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, BLKQ, BLKK, int(is_causal), int(Hq), int(Hkv), int(head_dim),
+                              int(pv_fp8), _p(cu_qs), _p(cu_ks), _p(order), _p(items), _p(slab_first), _p(slab_seq), _p(hdr),
+                              _stream(cu_seqlens_q))
     _cabi.check(rc, "sage_varlen_plan")
-    return cu_qs, cu_ks, order
+    return VarlenPlan(cu_qs, cu_ks, order, items, hdr, slab_first, slab_seq, items_bound, slab_bound)
 
 
 def per_block_int8_varlen(q, k, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, km=None,
-                          BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None, cu_ks: Optional[torch.Tensor] = None):
+                          BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None, cu_ks: Optional[torch.Tensor] = None,
+                          cu_qs: Optional[torch.Tensor] = None):
     """Packed ``[sum L, H, D]`` per-block quantisation (quant_per_block_varlen.py:60-104).
     ``km`` (``[1, H, D]`` or ``[H, D]``) is subtracted from k inside the kernel, rounded to the
-    input dtype exactly as the reference's ``k = k - km`` (core.py:432-434) does."""
-    k = _aligned(k, 8)
-    Hkv, D = k.shape[1], k.shape[-1]
+    input dtype exactly as the reference's ``k = k - km`` (core.py:432-434) does.  ``q`` or ``k`` may be None (one half only).
+    With the prefix arrays of a ``varlen_plan`` (``cu_qs`` / ``cu_ks``) the scale tensors are allocated at their host-known bounds
+    ``ceil(sum L / BLK) + nseq`` and nothing synchronises; without them they have the reference's exact shapes
+    (``cu_seqlens_*_scale[-1]`` rows: one host synchronisation each, as quant_per_block_varlen.py:75-76)."""
+    some = q if q is not None else k
+    D = some.shape[-1]
     if sm_scale is None:
         sm_scale = D ** -0.5
     nseq = cu_seqlens_k.shape[0] - 1
     cu_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_k = cu_seqlens_k.to(torch.int32).contiguous()
-    cu_qs = _cu_blocks(cu_q, BLKQ) if q is not None else None
-    if cu_ks is None:              # (sageattn_varlen passes the array of varlen_plan)
-        cu_ks = _cu_blocks(cu_k, BLKK)
-    # head-major storage behind the packed [sum L, H, D] view (see _quant)
-    k_int8 = torch.empty((Hkv, k.shape[0], D), dtype=torch.int8, device=k.device).permute(1, 0, 2)
     lib = _cabi.load()
-    q_int8 = q_scale = None        # q=None: the K half only (sage_attn_fused_qblock_pv_f16_varlen quantises Q in the attention kernel)
+    q_int8 = q_scale = k_int8 = k_scale = None
     if q is not None:
         q = _aligned(q, 8)
         Hq = q.shape[1]
+        # head-major storage behind the packed [sum L, H, D] view (see _quant)
         q_int8 = torch.empty((Hq, q.shape[0], D), dtype=torch.int8, device=q.device).permute(1, 0, 2)
-        # one host sync, as in the reference (`torch.empty((cu_seqlens_q_scale[-1], h_qo))`, :75)
-        nq = int(cu_qs[-1].item())
+        if cu_qs is None:
+            cu_qs = _cu_blocks(cu_q, BLKQ)
+            nq = int(cu_qs[-1].item())
+        else:
+            nq = (q.shape[0] + BLKQ - 1) // BLKQ + nseq
         q_scale = torch.empty((nq, Hq), dtype=torch.float32, device=q.device)
         rc = lib.sage_quant_qk_int8_varlen(_p(q), None, _p(q_int8), _p(q_scale), _p(cu_q), _p(cu_qs), nseq, int(max_seqlen_q),
                                            Hq, D, q.stride(0), q.stride(1), q_int8.stride(0), q_int8.stride(1), 0,
                                            BLKQ, float(sm_scale * LOG2E), _dtype_code(q), _stream(q))
         _cabi.check(rc, "sage_quant_qk_int8_varlen(q)")
-    # the public quantiser returns the reference's shapes (`cu_seqlens_k_scale[-1]`, one host sync, quant_per_block_varlen.py:75-76); the
-    # K-only form used by sageattn_varlen allocates the bound sum ceil(L_i / BLKK) <= ceil(sum L / BLKK) + nseq instead and never syncs
-    nk = int(cu_ks[-1].item()) if q is not None else (k.shape[0] + BLKK - 1) // BLKK + nseq
-    k_scale = torch.empty((nk, Hkv), dtype=torch.float32, device=k.device)
-    if km is not None:
-        km = km.reshape(Hkv, D).contiguous()
-    rc = lib.sage_quant_qk_int8_varlen(_p(k), _p(km), _p(k_int8), _p(k_scale), _p(cu_k), _p(cu_ks), nseq, int(max_seqlen_k),
-                                       Hkv, D, k.stride(0), k.stride(1), k_int8.stride(0), k_int8.stride(1), D,
-                                       BLKK, 1.0, _dtype_code(k), _stream(k))
-    _cabi.check(rc, "sage_quant_qk_int8_varlen(k)")
+    if k is not None:
+        k = _aligned(k, 8)
+        Hkv = k.shape[1]
+        k_int8 = torch.empty((Hkv, k.shape[0], D), dtype=torch.int8, device=k.device).permute(1, 0, 2)
+        if cu_ks is None:
+            cu_ks = _cu_blocks(cu_k, BLKK)
+            nk = int(cu_ks[-1].item())
+        else:
+            nk = (k.shape[0] + BLKK - 1) // BLKK + nseq
+        k_scale = torch.empty((nk, Hkv), dtype=torch.float32, device=k.device)
+        if km is not None:
+            km = km.reshape(Hkv, D).contiguous()
+        rc = lib.sage_quant_qk_int8_varlen(_p(k), _p(km), _p(k_int8), _p(k_scale), _p(cu_k), _p(cu_ks), nseq, int(max_seqlen_k),
+                                           Hkv, D, k.stride(0), k.stride(1), k_int8.stride(0), k_int8.stride(1), D,
+                                           BLKK, 1.0, _dtype_code(k), _stream(k))
+        _cabi.check(rc, "sage_quant_qk_int8_varlen(k)")
     return q_int8, q_scale, k_int8, k_scale, cu_qs, cu_ks
 
 
@@ -219,18 +259,26 @@ def channel_mean(x: torch.Tensor, tensor_layout: str = "HND") -> torch.Tensor:
 
 
 @_eager
-def channel_mean_packed(x: torch.Tensor) -> torch.Tensor:
-    """Mean over ALL tokens of a packed ``[sum L, H, D]`` tensor -> ``[1, H, D]`` (core.py:432-434)."""
+def channel_mean_packed(x: torch.Tensor, cu_seqlens: Optional[torch.Tensor] = None, plan: Optional["VarlenPlan"] = None) -> torch.Tensor:
+    """Mean over ALL tokens of a packed ``[sum L, H, D]`` tensor -> ``[1, H, D]`` (core.py:432-434).  With the slab map of a
+    ``varlen_plan`` the sum runs over the per-sequence 512-token slabs of the one-launch pre-pass (same bits as ``prepass_kv_varlen``);
+    without one over the packed tokens in slabs of 512."""
     x = _aligned(x, 8)
     T, H, D = x.shape
     out = torch.empty((1, H, D), dtype=x.dtype, device=x.device)
+    if plan is not None and plan.slab_seq is not None:
+        ws = _stats_ws(1, H, 512 * plan.slab_bound, D, x.device)
+        rc = _cabi.load().sage_channel_mean_varlen(_p(x), _p(out), _p(ws), _p(cu_seqlens), _p(plan.slab_first), _p(plan.slab_seq), _p(plan.hdr),
+                                                   T, plan.slab_bound, H, D, x.stride(0), x.stride(1), _dtype_code(x), _stream(x))
+        _cabi.check(rc, "sage_channel_mean_varlen")
+        return out
     ws = _stats_ws(1, H, T, D, x.device)
     rc = _cabi.load().sage_channel_mean(_p(x), _p(out), _p(ws), 1, H, T, D, 0, x.stride(1), x.stride(0), _dtype_code(x), _stream(x))
     _cabi.check(rc, "sage_channel_mean")
     return out
 
 
-_DEBUG = bool(int(__import__("os").environ.get("SAGE_DEBUG", "0") or 0))   # SAGE_DEBUG=1: check the pre-pass give-up flags after every call (synchronises)
+_DEBUG = bool(int(os.environ.get("SAGE_DEBUG", "0") or 0))   # SAGE_DEBUG=1: check the pre-pass give-up flags after every call (synchronises)
 
 
 @_eager
@@ -268,13 +316,54 @@ def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
     return n
 
 
+class _PrepassGuard:
+    """Per-device watch on the one-launch pre-pass's in-launch head barrier.  The barrier needs every slab of a head resident at once; the
+    C ABI bounds that by the compute units the launch stream may use, but it cannot see compute units that OTHER streams' kernels hold
+    (an RCCL kernel beside the attention stream).  A workgroup that waits in vain (~1 s) poisons its outputs with NaN and stores 1 into
+    this guard's pinned host word (``host_flag`` of ``sage_prepass_kv``).  The word is read -- a plain host memory read, no
+    synchronisation -- at the start of every later pre-pass on the device: once it is set the device's calls take the three-call sequence
+    for the rest of the process and a warning says that an earlier call returned NaN-poisoned output."""
+    _by_device: dict = {}
+
+    def __init__(self, device: torch.device):
+        with torch.cuda.device(device):
+            host, dev = ctypes.c_void_p(), ctypes.c_void_p()
+            _cabi.check(_cabi.load().sage_host_word_alloc(ctypes.byref(host), ctypes.byref(dev)), "sage_host_word_alloc")
+        self.host, self.ptr = host.value, dev.value          # lives as long as the process (one 64-byte pinned block per device)
+        self.tripped = False
+        self.device = device
+
+    @classmethod
+    def of(cls, device: torch.device) -> "_PrepassGuard":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        g = cls._by_device.get(idx)
+        if g is None:
+            g = cls._by_device[idx] = cls(torch.device("cuda", idx))
+        return g
+
+    def fused_allowed(self) -> bool:
+        if not self.tripped and ctypes.c_int32.from_address(self.host).value != 0:
+            self.tripped = True
+            warnings.warn(f"sageattention_amd: a one-launch K/V pre-pass on {self.device} gave up waiting for the other slabs of a head "
+                          "(compute units held by another stream?); the attention output of that call is NaN-poisoned.  This device's "
+                          "calls take the kernel sequence from now on.", RuntimeWarning, stacklevel=3)
+        return not self.tripped
+
+    def reset(self) -> None:          # tests
+        ctypes.c_int32.from_address(self.host).value = 0
+        self.tripped = False
+
+
 def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
-    """Whether the one-launch pre-pass covers this K / V length (the slabs of a head wait for each other in the launch)."""
+    """Whether the one-launch pre-pass covers this K / V length on the current stream (the slabs of a head wait for each other in the
+    launch: one per compute unit the stream may use, ``sage_prepass_max_seqlen_stream``) -- and has not failed on this device before."""
     _, _, L, D, _, _, sl = _dims(k, tensor_layout)
     # the kernel addresses one head with 32-bit buffer offsets (row stride x rows x 2 bytes)
     # (rows of the last 512-row slab past L go through the buffer range check: their offsets must not wrap either)
     lpad = (L + 511) // 512 * 512
-    return L <= int(_cabi.load().sage_prepass_max_seqlen()) and ((lpad - 1) * sl + D) * 2 < 2 ** 32
+    if ((lpad - 1) * sl + D) * 2 >= 2 ** 32 or not k.is_cuda:
+        return False
+    return L <= int(_cabi.load().sage_prepass_max_seqlen_stream(_stream(k))) and _PrepassGuard.of(k.device).fused_allowed()
 
 
 @_eager
@@ -325,7 +414,7 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     assert sync.dtype == torch.int32 and sync.numel() >= int(lib.sage_prepass_sync_words(B, H)) and sync.device == dev
     rc = lib.sage_prepass_kv(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(v_scale), _p(vm), _p(ws), _p(sync),
                              B, H, L, D, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, ob, oh, ol,
-                             BLKK, gran, style, float(scale_max), int(bool(v_fp16)), _dtype_code(k), _stream(k))
+                             BLKK, gran, style, float(scale_max), int(bool(v_fp16)), _dtype_code(k), _PrepassGuard.of(dev).ptr, _stream(k))
     _cabi.check(rc, "sage_prepass_kv")
     if _DEBUG:
         n = prepass_failed_heads(sync, B, H)
@@ -333,6 +422,58 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
             raise _cabi.SageKernelError(f"sage_prepass_kv: {n} (K|V, batch, head) entries gave up waiting for the other slabs of "
                                         "their head (outputs are NaN-poisoned); is the stream restricted to few compute units?")
     return km, k_int8, k_scale, v_image, v_scale, vm
+
+
+def prepass_varlen_fused_ok(k: torch.Tensor, plan: Optional["VarlenPlan"], max_seqlen_k: int, smooth_k: bool = True) -> bool:
+    """Whether ``prepass_kv_varlen`` takes this packed batch: a slab map from ``varlen_plan``; with ``smooth_k`` every slab of a head --
+    all sequences -- waits for the others inside the launch, so the host-known bound of their number must not exceed 128 nor the
+    compute units of the stream; 32-bit offsets inside one sequence of one head."""
+    if plan is None or plan.slab_seq is None or not k.is_cuda:
+        return False
+    lpad = (int(max_seqlen_k) + 511) // 512 * 512
+    if ((lpad - 1) * k.stride(0) + k.shape[-1]) * 2 >= 2 ** 32:
+        return False
+    if not smooth_k:
+        return True
+    return 512 * plan.slab_bound <= int(_cabi.load().sage_prepass_max_seqlen_stream(_stream(k))) and _PrepassGuard.of(k.device).fused_allowed()
+
+
+@_eager
+def prepass_kv_varlen(k: torch.Tensor, v: Optional[torch.Tensor], cu_seqlens_k: torch.Tensor, plan: "VarlenPlan", max_seqlen_k: int,
+                      smooth_k: bool = True, sync: Optional[torch.Tensor] = None):
+    """The K / V pre-pass of ``sageattn_varlen`` (core.py:431-444) in ONE launch that reads K and V once (``sage_prepass_kv_varlen``):
+    ``km = k.mean(dim=0)`` over all packed tokens, per-sequence INT8 ``k - km`` with one scale per 64 keys (Triton rounding), the fp16 V
+    tile image.  Returns ``(km [1, H, D] | None, k_int8 [sum L, H, D] (head-major storage), k_scale [nblk_bound, H], v_image | None)`` --
+    the bits of ``channel_mean_packed(plan)`` + ``per_block_int8_varlen`` (K half) + ``prep_v_fp16_varlen``."""
+    k = _aligned(k, 8)
+    T, H, D = k.shape
+    dev = k.device
+    nseq = cu_seqlens_k.shape[0] - 1
+    k_int8 = torch.empty((H, T, D), dtype=torch.int8, device=dev).permute(1, 0, 2)
+    nblk = (T + 63) // 64 + nseq
+    k_scale = torch.empty((nblk, H), dtype=torch.float32, device=dev)
+    km = torch.empty((1, H, D), dtype=k.dtype, device=dev) if smooth_k else None
+    v_image = None
+    v_sl = v_sh = 0
+    if v is not None:
+        v = _aligned(v, 8)
+        assert v.shape == k.shape and v.dtype == k.dtype, "k and v must have one shape and dtype"
+        v_sl, v_sh = v.stride(0), v.stride(1)
+        v_image = torch.empty((nblk, H, D, 64), dtype=torch.float16, device=dev)
+    lib = _cabi.load()
+    ws = torch.empty((int(lib.sage_prepass_ws_floats(1, H, 512 * plan.slab_bound, D)),), dtype=torch.float32, device=dev)
+    if sync is None:
+        sync = _prepass_sync(1, H, dev)
+    rc = lib.sage_prepass_kv_varlen(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(ws), _p(sync), _p(cu_seqlens_k),
+                                    _p(plan.cu_ks), _p(plan.slab_first), _p(plan.slab_seq), _p(plan.hdr), nseq, T, int(max_seqlen_k),
+                                    plan.slab_bound, H, D, k.stride(0), k.stride(1), v_sl, v_sh, k_int8.stride(0), k_int8.stride(1),
+                                    _dtype_code(k), _PrepassGuard.of(dev).ptr, _stream(k))
+    _cabi.check(rc, "sage_prepass_kv_varlen")
+    if _DEBUG:
+        n = prepass_failed_heads(sync, 1, H)
+        if n:
+            raise _cabi.SageKernelError(f"sage_prepass_kv_varlen: {n} heads gave up waiting for their other slabs (outputs are NaN-poisoned)")
+    return km, k_int8, k_scale, v_image
 
 
 @_eager

@@ -55,9 +55,26 @@ def test_argument_errors_do_not_need_a_gpu():
     rc = lib.sage_merge_states(p, None, p, p, None, 1, 1, 4, 16, 0, 0, 16, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"null" in lib.sage_last_error()
     # varlen attention needs its prefix arrays
-    rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, None, None, None, None, None, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
+    rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, None, None, None, None, None, None, None, 0, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
                                              0, 1.0, 1, 0, None)
     assert rc == -1 and b"varlen" in lib.sage_last_error()
+    # a work list comes with its header and a positive bound
+    rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, p, p, p, p, None, p, None, 4, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
+                                             0, 1.0, 1, 0, None)
+    assert rc == -1 and b"work list" in lib.sage_last_error()
+    # the varlen plan: sequence count, and the work list needs the attention kernel's block sizes
+    rc = lib.sage_varlen_plan(p, p, 5000, 128, 64, 0, 8, 8, 128, 0, None, p, p, None, None, None, None, None)
+    assert rc == -1 and b"nseq" in lib.sage_last_error()
+    rc = lib.sage_varlen_plan(p, p, 4, 64, 64, 0, 8, 8, 128, 0, None, p, p, p, None, None, p, None)
+    assert rc == -1 and b"work list" in lib.sage_last_error()
+    # the work-order debug view checks every argument (a zero block count used to divide by zero)
+    h, r = ctypes.c_int(), ctypes.c_int()
+    assert lib.sage_debug_work_item(0, 8, 8, 0, 2, 0, 0, ctypes.byref(h), ctypes.byref(r)) == -1
+    assert lib.sage_debug_work_item(0, 8, 8, 4, 2, 0, 9, ctypes.byref(h), ctypes.byref(r)) == -1
+    # the one-launch varlen pre-pass refuses more slabs per head than can wait for each other
+    rc = lib.sage_prepass_kv_varlen(p, p, p, p, p, p, p, p, p, p, p, p, p, 4, 512 * 200, 512, 204, 2, 128, 256, 128, 256, 128, 128, 512 * 200 * 128,
+                                    0, None, None)
+    assert rc == -1
 
 
 def test_v_image_bytes():

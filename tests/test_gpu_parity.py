@@ -653,6 +653,12 @@ def test_config3_full_vs_oracle(oracle_mod):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
 
 
+def _varlen_km(k, cu_q, cu_k):
+    """The K mean of a sageattn_varlen call as the call forms it: over all packed tokens, summed over the per-sequence slabs of its plan."""
+    plan = sq.varlen_plan(cu_q, cu_k, total_q=int(cu_q[-1].item()), total_k=k.shape[0])
+    return sq.channel_mean_packed(k, cu_k, plan)
+
+
 @pytest.mark.parametrize("causal", [True, False])
 def test_config4_full_vs_oracle(oracle_mod, causal):
     """BASELINE.json configs[3]: sageattn_varlen, Hq=32 Hkv=8 D=128 bf16, all eight sequences 256..16384 (one ragged).
@@ -667,7 +673,7 @@ def test_config4_full_vs_oracle(oracle_mod, causal):
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     o = sa.sageattn_varlen(qd, kd, vd, cu.to(DEV), cu.to(DEV), max(lens), max(lens), is_causal=causal)
     torch.cuda.synchronize()
-    km = util.bits(sq.channel_mean_packed(kd))                      # [1, Hkv, D]: the mean over ALL packed tokens
+    km = util.bits(_varlen_km(kd, cu.to(DEV), cu.to(DEV)))          # [1, Hkv, D]: the mean over ALL packed tokens
     hq, hk = (32, 8) if causal else (8, 2)
     ref = oracle_mod.sageattn_varlen(util.bits(q[:, :hq]), util.bits(k[:, :hk]), util.bits(v[:, :hk]), 1, cu.numpy(), cu.numpy(),
                                      is_causal=causal, km=np.ascontiguousarray(km[:, :hk]))
@@ -720,7 +726,7 @@ def test_varlen_cu_q_differs_from_cu_k(oracle_mod, name):
     assert (q8.cpu().numpy() == z["q_int8"]).all() and (qs.cpu().numpy() == z["q_scale"]).all()
     assert (k8.cpu().numpy() == z["k_int8"]).all() and (ks.cpu().numpy() == z["k_scale"]).all()
     ref_o = oracle_mod.sageattn_varlen(z["q"], z["k"], z["v"], dt, z["cu_q"], z["cu_k"], is_causal=bool(causal),
-                                       km=util.bits(sq.channel_mean_packed(k)))
+                                       km=util.bits(_varlen_km(k, cu_q, cu_k)))
     _assert_vs_oracle(f"varlen_cross/{name}", got, ref_o, dt)
 
 
@@ -1079,20 +1085,136 @@ def test_varlen_fused_per_block_q_quant_is_bit_identical(causal, dt, D, hq, hkv)
 
 
 def test_varlen_plan_matches_the_torch_prefix_sums():
-    """sage_varlen_plan (one launch) against the reference's torch ops (quant_per_block_varlen.py:68-73) and a sort by length."""
+    """sage_varlen_plan (one launch) against the reference's torch ops (quant_per_block_varlen.py:68-73), a sort by length, and -- the work
+    list, its header and the slab map -- against the same functions run on the host (sage_debug_varlen_items) and numpy."""
+    import ctypes
+    from sageattention_amd import _cabi
+    lib = _cabi.load()
     g = torch.Generator().manual_seed(5)
     for nseq in (1, 2, 7, 64, 333, 1024):
-        lq = torch.randint(0, 5000, (nseq,), generator=g)
-        lk = torch.randint(0, 5000, (nseq,), generator=g)
+        lq = torch.randint(0, 5000 if nseq < 300 else 700, (nseq,), generator=g)
+        lk = torch.randint(0, 5000 if nseq < 300 else 700, (nseq,), generator=g)
         lq[0] = lq[-1]                                                 # a tie
         cu_q = torch.nn.functional.pad(lq.cumsum(0), (1, 0)).to(torch.int32).to(DEV)
         cu_k = torch.nn.functional.pad(lk.cumsum(0), (1, 0)).to(torch.int32).to(DEV)
-        cu_qs, cu_ks, order = sq.varlen_plan(cu_q, cu_k, want_q_blocks=True)
-        assert torch.equal(cu_qs.cpu(), torch.nn.functional.pad(((lq + 127) // 128).cumsum(0), (1, 0)).to(torch.int32))
-        assert torch.equal(cu_ks.cpu(), torch.nn.functional.pad(((lk + 63) // 64).cumsum(0), (1, 0)).to(torch.int32))
-        o = order.cpu().long()
-        assert sorted(o.tolist()) == list(range(nseq)) and (lq[o][:-1] >= lq[o][1:]).all()
+        for causal, hq, hkv in ((False, 8, 2), (True, 12, 4)):
+            plan = sq.varlen_plan(cu_q, cu_k, want_q_blocks=True, total_q=int(lq.sum()), total_k=int(lk.sum()), is_causal=causal,
+                                  Hq=hq, Hkv=hkv, head_dim=128)
+            assert torch.equal(plan.cu_qs.cpu(), torch.nn.functional.pad(((lq + 127) // 128).cumsum(0), (1, 0)).to(torch.int32))
+            assert torch.equal(plan.cu_ks.cpu(), torch.nn.functional.pad(((lk + 63) // 64).cumsum(0), (1, 0)).to(torch.int32))
+            o = plan.order.cpu().long()
+            assert sorted(o.tolist()) == list(range(nseq)) and (lq[o][:-1] >= lq[o][1:]).all()
+            nslab = (lk + 511) // 512
+            assert torch.equal(plan.slab_first.cpu(), torch.nn.functional.pad(nslab.cumsum(0), (1, 0)).to(torch.int32))
+            assert torch.equal(plan.slab_seq.cpu()[:int(nslab.sum())], torch.repeat_interleave(torch.arange(nseq), nslab).to(torch.int32))
+            hdr = plan.hdr.cpu().numpy()
+            nitems = int(((lq + 127) // 128).sum())
+            assert hdr[0] == nitems <= plan.items_bound and hdr[4] == int(nslab.sum()) <= plan.slab_bound
+            assert hdr[5] == int(lk.max()) and hdr[6] == int(lk.sum())
+            lqa, lka = lq.numpy().astype(np.int32), lk.numpy().astype(np.int32)
+            items = np.zeros((max(nitems, 1), 2), np.int32)
+            hh = np.zeros(8, np.int32)
+            grid = lib.sage_debug_varlen_items(lqa.ctypes.data_as(ctypes.c_void_p), lka.ctypes.data_as(ctypes.c_void_p), nseq, int(causal), hq, hkv,
+                                               128, 0, items.ctypes.data_as(ctypes.c_void_p), max(nitems, 1), hh.ctypes.data_as(ctypes.c_void_p))
+            assert grid >= 0 and (hh[:4] == hdr[:4]).all()
+            assert (plan.items.cpu().numpy()[:nitems] == items[:nitems]).all()
     assert sq.varlen_plan(torch.zeros(1026, dtype=torch.int32, device=DEV), torch.zeros(1026, dtype=torch.int32, device=DEV)) is None
+
+
+_VARLEN_SETS = [([1, 127, 128, 129, 700, 64, 1000], None), ([512, 513, 2048, 5, 1536], None), ([300], None), ([4096, 100, 4000], None),
+                ([1, 127, 128, 129, 700, 64, 1000], [5, 64, 200, 77, 1000, 640, 3])]
+
+
+@pytest.mark.parametrize("dt,D,hkv", [(1, 128, 2), (0, 64, 4), (0, 128, 1)])
+@pytest.mark.parametrize("smooth_k", [True, False])
+def test_varlen_one_launch_prepass_is_bit_identical_to_the_sequence(dt, D, hkv, smooth_k):
+    """sage_prepass_kv_varlen (K mean over all packed tokens + per-sequence INT8 K + fp16 V image, one launch, K and V read once) against
+    channel_mean_packed(plan) + per_block_int8_varlen + prep_v_fp16_varlen: every output bit, ragged lengths, slabs of several sequences."""
+    T = torch.float16 if dt == 0 else torch.bfloat16
+    for lens, klens in _VARLEN_SETS:
+        klens = klens or lens
+        total = sum(klens)
+        g = torch.Generator().manual_seed(77 + total)
+        k = (torch.randn(total, hkv, D, generator=g) * 1.5 + 2.0 * torch.randn(1, hkv, D, generator=g)).to(T).to(DEV)
+        v = torch.randn(total, hkv, D, generator=g).to(T).to(DEV)
+        cu_q = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+        cu_k = torch.tensor([0] + list(np.cumsum(klens)), dtype=torch.int32, device=DEV)
+        plan = sq.varlen_plan(cu_q, cu_k, total_q=sum(lens), total_k=total, Hq=hkv, Hkv=hkv, head_dim=D)
+        assert sq.prepass_varlen_fused_ok(k, plan, max(klens), smooth_k)
+        sync = torch.empty(int(sq._cabi.load().sage_prepass_sync_words(1, hkv)), dtype=torch.int32, device=DEV)
+        km1, k81, ks1, img1 = sq.prepass_kv_varlen(k, v, cu_k, plan, max(klens), smooth_k=smooth_k, sync=sync)
+        assert sq.prepass_failed_heads(sync, 1, hkv) == 0
+        km0 = sq.channel_mean_packed(k, cu_k, plan) if smooth_k else None
+        _, _, k80, ks0, _, _ = sq.per_block_int8_varlen(None, k, cu_q, cu_k, max(lens), max(klens), km=km0, cu_ks=plan.cu_ks)
+        img0 = sq.prep_v_fp16_varlen(v, cu_k, plan.cu_ks, max(klens), ntiles=img1.shape[0])
+        torch.cuda.synchronize()
+        nblk = int(plan.cu_ks[-1].item())
+        if smooth_k:
+            assert torch.equal(km1.view(torch.int16), km0.view(torch.int16))
+            want = k.float().mean(dim=0, keepdim=True)              # and it IS the mean (one rounding of an fp32 sum)
+            assert (km1.float() - want).abs().max().item() <= 2.0 ** (-7 if dt == 1 else -10) * max(1.0, want.abs().max().item())
+        assert torch.equal(k81, k80) and torch.equal(ks1[:nblk].view(torch.int32), ks0[:nblk].view(torch.int32))
+        assert torch.equal(img1[:nblk].view(torch.int16), img0[:nblk].view(torch.int16))
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dt,D,hq,hkv", [(1, 128, 8, 2), (0, 64, 12, 4), (0, 128, 3, 1)])
+def test_varlen_routes_are_bit_identical(causal, dt, D, hq, hkv):
+    """sageattn_varlen's default route (plan launch + one-launch K / V pre-pass + attention over the device-built work list) against the
+    kernel sequence, against the unit order sized by max_seqlen_q, and against both: same bits; and no host synchronisation."""
+    T = torch.float16 if dt == 0 else torch.bfloat16
+    for lens, klens in _VARLEN_SETS:
+        if causal and klens is not None:
+            continue
+        klens = klens or lens
+        g = torch.Generator().manual_seed(1234 + sum(lens))
+        q = torch.randn(sum(lens), hq, D, generator=g).to(T).to(DEV)
+        k = (torch.randn(sum(klens), hkv, D, generator=g) + torch.randn(1, hkv, D, generator=g)).to(T).to(DEV)
+        v = torch.randn(sum(klens), hkv, D, generator=g).to(T).to(DEV)
+        cu_q = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+        cu_k = torch.tensor([0] + list(np.cumsum(klens)), dtype=torch.int32, device=DEV)
+        args = (q, k, v, cu_q, cu_k, max(lens), max(klens))
+        o = sa.sageattn_varlen(*args, is_causal=causal)
+        o_seq = sa.sageattn_varlen(*args, is_causal=causal, fused_prepass=False)
+        o_unit = sa.sageattn_varlen(*args, is_causal=causal, work_list=False)
+        o_both = sa.sageattn_varlen(*args, is_causal=causal, fused_prepass=False, work_list=False, fuse_q_quant=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all()
+        assert torch.equal(o, o_seq) and torch.equal(o, o_unit) and torch.equal(o, o_both)
+
+
+def test_varlen_with_more_sequences_than_the_plan_takes(oracle_mod):
+    """More than sage_varlen_plan_max_seqs() sequences: no plan, so torch prefix sums, an on-device argsort for the unit order, the kernel
+    sequence, the Q quantiser fused in the attention prologue -- exercised end to end (round 3 only checked that the planner returns None).
+    smooth_k=False makes the sequences independent of each other: the call must equal, bit for bit, two planned calls over its halves;
+    smooth_k=True is checked against the oracle."""
+    g = torch.Generator().manual_seed(99)
+    nseq = 1100
+    lens = torch.randint(1, 150, (nseq,), generator=g)
+    lens[7] = 700
+    hq, hkv, D = 4, 2, 64
+    total = int(lens.sum())
+    q = torch.randn(total, hq, D, generator=g).half()
+    k = (torch.randn(total, hkv, D, generator=g) + torch.randn(1, hkv, D, generator=g)).half()
+    v = torch.randn(total, hkv, D, generator=g).half()
+    cu = torch.nn.functional.pad(lens.cumsum(0), (1, 0)).to(torch.int32)
+    qd, kd, vd, cud = q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV)
+    assert sq.varlen_plan(cud, cud, total_q=total, total_k=total) is None
+    for causal in (False, True):
+        o = sa.sageattn_varlen(qd, kd, vd, cud, cud, int(lens.max()), int(lens.max()), is_causal=causal, smooth_k=False)
+        half = 550
+        t0 = int(cu[half])
+        o_a = sa.sageattn_varlen(qd[:t0], kd[:t0], vd[:t0], cud[:half + 1].contiguous(), cud[:half + 1].contiguous(), int(lens[:half].max()),
+                                 int(lens[:half].max()), is_causal=causal, smooth_k=False)
+        cub = (cud[half:] - cud[half]).contiguous()
+        o_b = sa.sageattn_varlen(qd[t0:], kd[t0:], vd[t0:], cub, cub, int(lens[half:].max()), int(lens[half:].max()), is_causal=causal, smooth_k=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all() and torch.equal(o[:t0], o_a) and torch.equal(o[t0:], o_b)
+    o = sa.sageattn_varlen(qd, kd, vd, cud, cud, int(lens.max()), int(lens.max()), is_causal=True)
+    torch.cuda.synchronize()
+    km = util.bits(sq.channel_mean_packed(kd))                      # no plan: the packed-token partition
+    ref = oracle_mod.sageattn_varlen(util.bits(q), util.bits(k), util.bits(v), 0, cu.numpy(), cu.numpy(), is_causal=True, km=km)
+    _assert_vs_oracle("varlen_1100_sequences_causal", o.float().cpu().numpy(), ref, 0)
 
 
 def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():

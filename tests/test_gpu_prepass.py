@@ -263,9 +263,105 @@ def test_a_pre_pass_that_gives_up_is_loud():
         assert torch.isfinite(r1[2]).all() and torch.isfinite(r1[4]).all()
     finally:
         lib.sage_debug_prepass_fail(0)
+        quant._PrepassGuard.of(k.device).reset()            # (the guard's behaviour is the next test's subject)
     again = sa.sageattn(q, k, v, is_causal=False)
     torch.cuda.synchronize()
     assert torch.equal(again, want)
+
+
+def test_a_give_up_reroutes_the_device_to_the_kernel_sequence():
+    """Production behaviour (no SAGE_DEBUG): the workgroup that gives up also sets the caller's pinned host word; the next call on the
+    device reads it (no synchronisation), warns once and takes the kernel sequence from then on -- its output is correct, and so is
+    every later one, although the (forced) cause persists."""
+    import warnings
+    import sageattention_amd as sa
+    lib = _cabi.load()
+    q = torch.randn(1, 4, 1024, 128, device="cuda", dtype=torch.float16)
+    k, v = _mk(1, 4, 1024, 128, torch.float16, "HND", 5)
+    want = sa.sageattn(q, k, v, is_causal=True)
+    qv = torch.randn(1500, 4, 128, device="cuda", dtype=torch.bfloat16)
+    kv, vv = (torch.randn(1500, 2, 128, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    cu = torch.tensor([0, 700, 1500], dtype=torch.int32, device="cuda")
+    want_v = sa.sageattn_varlen(qv, kv, vv, cu, cu, 800, 800, is_causal=True)
+    torch.cuda.synchronize()
+    guard = quant._PrepassGuard.of(k.device)
+    guard.reset()
+    lib.sage_debug_prepass_fail(1)
+    try:
+        first = sa.sageattn(q, k, v, is_causal=True)                      # poisoned: its pre-pass gives up
+        torch.cuda.synchronize()
+        assert torch.isnan(first.float()).all()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            second = sa.sageattn(q, k, v, is_causal=True)
+            third = sa.sageattn(q, k, v, is_causal=True)
+            vl = sa.sageattn_varlen(qv, kv, vv, cu, cu, 800, 800, is_causal=True)
+            torch.cuda.synchronize()
+        assert len([x for x in w if "NaN-poisoned" in str(x.message)]) == 1, [str(x.message) for x in w]
+        assert guard.tripped and not quant.prepass_fused_ok(k)
+        assert torch.equal(second, want) and torch.equal(third, want) and torch.equal(vl, want_v)
+    finally:
+        lib.sage_debug_prepass_fail(0)
+        guard.reset()
+    assert quant.prepass_fused_ok(k)
+
+
+def _cu_mask_stream(ncus_lo, ncus_hi):
+    """A torch stream restricted to compute units [ncus_lo, ncus_hi) of XCD-interleaved numbering (hipExtStreamCreateWithCUMask)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for c in range(ncus_lo, ncus_hi):
+        mask[c // 32] |= 1 << (c % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(st.value), st, hip
+
+
+def test_compute_units_held_by_another_stream_cost_one_call_not_the_process():
+    """What the co-residency bound cannot see: sageattn() runs on a stream restricted to 8 compute units (so its heads may have 8 slabs)
+    while a kernel on a second stream holds six of those eight for seconds.  The first call's pre-pass cannot get the slabs of a head
+    resident together, gives up and returns NaN; from the second call on the device takes the kernel sequence: correct output, no
+    SAGE_DEBUG, no hang."""
+    import warnings
+    import sageattention_amd as sa
+    lib = _cabi.load()
+    q = torch.randn(1, 2, 4096, 128, device="cuda", dtype=torch.bfloat16)
+    k, v = _mk(1, 2, 4096, 128, torch.bfloat16, "HND", 31)            # 8 slabs per head
+    want = sa.sageattn(q, k, v, is_causal=True)
+    torch.cuda.synchronize()
+    guard = quant._PrepassGuard.of(k.device)
+    guard.reset()
+    s8, h8, hip = _cu_mask_stream(0, 8)
+    s6, h6, _ = _cu_mask_stream(0, 6)
+    try:
+        with torch.cuda.stream(s8):
+            assert quant.prepass_fused_ok(k) and int(lib.sage_prepass_max_seqlen_stream(s8.cuda_stream)) == 8 * 512
+            assert not quant.prepass_fused_ok(_mk(1, 1, 8192, 128, torch.bfloat16, "HND", 1)[0])     # 16 slabs: the sequence, by the stream-aware bound
+        # two 1024-thread workgroups fill a compute unit's wave slots: 12 of them hold the six units for 2.5 s
+        assert lib.sage_debug_spin(2500, 12, s6.cuda_stream) == 0
+        with torch.cuda.stream(s8):
+            first = sa.sageattn(q, k, v, is_causal=True)
+        s8.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(s8):
+                second = sa.sageattn(q, k, v, is_causal=True)
+                third = sa.sageattn(q, k, v, is_causal=True)
+            torch.cuda.synchronize()
+        if torch.isnan(first.float()).any():                   # the contention did bite (it does on an otherwise idle MI355X)
+            assert guard.tripped and len([x for x in w if "NaN-poisoned" in str(x.message)]) == 1
+        else:                                                  # the hardware found room after all: then nothing may have changed
+            assert not guard.tripped and torch.equal(first, want)
+        assert torch.equal(second, want) and torch.equal(third, want)
+    finally:
+        torch.cuda.synchronize()
+        guard.reset()
+        hip.hipStreamDestroy(h8)
+        hip.hipStreamDestroy(h6)
 
 
 @pytest.mark.parametrize("D,causal,layout,dtype,pv_accum,smooth_v,gqa", [

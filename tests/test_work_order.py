@@ -76,3 +76,68 @@ def test_group_size_rule_on_the_baseline_shapes():
     assert plan(64, 64)[2] == 0 and plan(64, 8)[2] == 1 and plan(64, 8, head_dim=64)[2] == 0     # fold: single-round grids, two workgroups per CU
     lib = _cabi.load()
     assert lib.sage_debug_work_item(5, 4, 1, 4, 1, 0, 0, None, None) == -1
+
+
+# ---- packed (varlen) batches: the device-built work list, run on the host through sage_debug_varlen_items ------------------------------
+def varlen_items(lq, lk, causal, hq, hkv, head_dim=128):
+    import numpy as np
+    lib = _cabi.load()
+    lqa, lka = np.asarray(lq, np.int32), np.asarray(lk, np.int32)
+    n = int(((lqa + 127) // 128).sum())
+    out = np.zeros((max(n, 1), 2), np.int32)
+    hdr = np.zeros(8, np.int32)
+    grid = lib.sage_debug_varlen_items(lqa.ctypes.data_as(ctypes.c_void_p), lka.ctypes.data_as(ctypes.c_void_p), len(lq), int(causal), hq, hkv,
+                                       head_dim, 0, out.ctypes.data_as(ctypes.c_void_p), max(n, 1), hdr.ctypes.data_as(ctypes.c_void_p))
+    assert grid >= 0 and hdr[0] == n
+    return [tuple(x) for x in out[:n]], hdr[:4].tolist(), grid
+
+
+def _weight(lk, j, causal):
+    ntk = (lk + 63) // 64
+    return min(ntk, 2 * j + 2) if causal else ntk
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_work_list_is_every_query_block_once_heaviest_first(causal):
+    import random
+    rnd = random.Random(3)
+    cases = [([256, 512, 1000, 1024, 2048, 4096, 8192, 16384],) * 2, ([1, 127, 128, 129, 700, 64, 1000], [5, 64, 200, 77, 1000, 640, 3]),
+             ([0, 300, 0], [10, 300, 5]), ([128] * 40,) * 2]
+    cases += [([rnd.randrange(0, 3000) for _ in range(n)], [rnd.randrange(0, 3000) for _ in range(n)]) for n in (1, 2, 9, 33, 200)]
+    for lq, lk in cases:
+        its, (nitems, grp, fold, left), grid = varlen_items(lq, lk, causal, 32, 8)
+        want = [(s, j) for s in range(len(lq)) for j in range((lq[s] + 127) // 128)]
+        assert sorted(its) == want                                                       # a permutation of the blocks that exist
+        w = [_weight(lk[s], j, causal) for s, j in its]
+        assert all(a >= b for a, b in zip(w, w[1:]))                                     # heaviest first
+        # ties: sequence index ascending, then the later block first (a total order: the device and the host agree on it)
+        assert all((w[i] > w[i + 1]) or (its[i][0] < its[i + 1][0]) or (its[i][0] == its[i + 1][0] and its[i][1] > its[i + 1][1])
+                   for i in range(len(its) - 1))
+
+
+def test_varlen_launch_deals_every_head_item_pair_once_and_keeps_gqa_groups_on_one_xcd():
+    for lq, hq, hkv, head_dim in [([256, 512, 1000, 1024, 2048, 4096, 8192, 16384], 32, 8, 128), ([700, 64, 1000, 3], 12, 4, 64),
+                                  ([5000], 4, 1, 128), ([128] * 9, 8, 8, 128), ([300, 200], 28, 4, 128), ([100] * 50, 64, 8, 128)]:
+        for causal in (False, True):
+            its, (nitems, grp, fold, left), grid = varlen_items(lq, lq, causal, hq, hkv, head_dim)
+            assert grid == 8 * (left * ((nitems + 7) // 8) + (hq // 8) * nitems) and left == hq % 8
+            gqa = hq // hkv
+            assert grp >= 1 and (hq // 8 == 0 or grp % gqa == 0 or grp == hq // 8)       # whole GQA groups (or every head the XCD owns)
+            got = [it for it in items(hq, nitems, grp, left, fold, grid) if it is not None]
+            assert len(got) == len(set(got)) == hq * nitems
+            # a head that an XCD owns stays on it: its K/V (all sequences) streams through one L2
+            owner = {}
+            for bid, it in enumerate(items(hq, nitems, grp, left, fold, grid)):
+                if it is not None and it[0] >= left:
+                    assert owner.setdefault(it[0], bid & 7) == bid & 7
+            if hq >= 8 and (hq // 8) % gqa == 0 and left == 0:
+                for h, x in owner.items():
+                    assert owner[(h // gqa) * gqa] == x                                    # the query heads of one kv head share the XCD
+
+
+def test_c4_work_list_shape():
+    """BASELINE.json configs[3]: 262 query blocks in all, 8384 workgroups (the grid sized by max_seqlen_q launched 32768)."""
+    lens = [256, 512, 1000, 1024, 2048, 4096, 8192, 16384]
+    its, (nitems, grp, fold, left), grid = varlen_items(lens, lens, True, 32, 8)
+    assert nitems == 262 and grid == 8 * 4 * 262 and left == 0 and grp == 4 and fold == 0
+    assert its[0] == (7, 127) and its[1] == (7, 126)
