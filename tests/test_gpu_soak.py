@@ -1,9 +1,9 @@
-"""Soak of the hand-scheduled kernels (GPU): the steady-state loops of csrc/sage_attn.hip and csrc/sage_attn64.hip pin their
+"""Soak of the hand-scheduled kernels (GPU): the steady-state loops of csrc/sage_attn.hip pin their
 instruction order in asm and manage their own hazards and LDS ring, so a missed hazard or a race shows up as a lane-, wave- or
 tile-sized difference between two identical calls, rarely (round 2 shipped one that appeared once in a few hundred launches).
 
 For every pipelined instantiation that a public entry point reaches -- FP8 PV D=128 / 64, causal / not, INT8-Q and fused-Q (fp16, bf16)
-routes, FP16 PV D=128 / 64 in its CUDA and Triton forms, the split-KV route, the 256-row kernel -- 200 launches, alternating between two
+routes, FP16 PV D=128 / 64 in its CUDA and Triton forms, the split-KV route, the packed (varlen) route -- 200 launches, alternating between two
 streams while a GEMM competes for the CUs, must equal the first launch bit for bit; and a call whose every temporary lands in
 NaN-poisoned memory must equal a call on clean memory (nothing reads what it has not written).
 """
@@ -27,7 +27,7 @@ def _qkv(B, Hq, Hkv, Lq, Lk, D, dtype, seed):
 
 
 F16, BF16 = torch.float16, torch.bfloat16
-# name, entry point, kwargs, (B, Hq, Hkv, Lq, Lk, D, dtype), attn64 mode
+# name, entry point, kwargs, (B, Hq, Hkv, Lq, Lk, D, dtype), (unused)
 CASES = [
     ("f8_d128_causal_fusedq_bf16", "sageattn", dict(is_causal=True), (2, 8, 4, 2048, 2048, 128, BF16), 0),
     ("f8_d128_noncausal_fusedq_f16", "sageattn", dict(is_causal=False), (1, 8, 8, 2048, 2048, 128, F16), 0),
@@ -47,9 +47,6 @@ CASES = [
     ("f16_d64_triton_form_noncausal", "triton", dict(is_causal=False), (1, 8, 8, 2048, 2048, 64, BF16), 0),
     ("f8_split_kv_cross_attention", "fp8", dict(is_causal=False, qk_quant_gran="per_thread", pv_accum_dtype="fp32+fp32", split_kv=4),
      (1, 8, 8, 128, 4096, 128, BF16), 0),
-    ("f8_d128_causal_256row_kernel", "sageattn", dict(is_causal=True), (2, 8, 4, 2048, 2048, 128, BF16), 1),
-    ("f8_d128_noncausal_256row_kernel_int8q", "fp8", dict(is_causal=False, qk_quant_gran="per_thread", pv_accum_dtype="fp32+fp32", fuse_q_quant=False),
-     (1, 8, 8, 2048, 2048, 128, F16), 1),
 ]
 
 
@@ -62,16 +59,12 @@ def _fn(entry):
 def route():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    lib = _cabi.load()
-    old = lib.sage_attn64_mode()
-    yield lib
-    lib.sage_set_attn64_mode(old)
+    return _cabi.load()
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_200_launches_on_two_streams_are_bit_identical(route, case):
     name, entry, kw, shape, mode = case
-    route.sage_set_attn64_mode(mode)
     q, k, v = _qkv(*shape, seed=len(name))
     fn = _fn(entry)
     first = fn(q, k, v, **kw)
@@ -91,12 +84,11 @@ def test_200_launches_on_two_streams_are_bit_identical(route, case):
     assert bad == 0, f"{name}: {bad} of 200 launches differ from the first"
 
 
-@pytest.mark.parametrize("case", [CASES[i] for i in (0, 4, 6, 9, 11, 12)], ids=[CASES[i][0] for i in (0, 4, 6, 9, 11, 12)])
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 4, 6, 9, 11)], ids=[CASES[i][0] for i in (0, 4, 6, 9, 11)])
 def test_results_do_not_depend_on_what_the_allocator_hands_out(route, case):
     """Every temporary of the call (quantised operands, scales, V image, workspaces, partial outputs) is allocated with torch.empty.
     Once with the caching allocator's free blocks full of NaN patterns, once full of 0x5A bytes: same bits as a call on fresh memory."""
     name, entry, kw, shape, mode = case
-    route.sage_set_attn64_mode(mode)
     q, k, v = _qkv(*shape, seed=3 + len(name))
     fn = _fn(entry)
     want = fn(q, k, v, **kw).clone()

@@ -27,22 +27,54 @@ def flops(B, H, N, D, causal):
     return 4.0 * B * H * N * N * D / (2 if causal else 1)
 
 
+def best_of(fn, n=3, warm=1):
+    for _ in range(warm):
+        fn()
+    best = float("inf")
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def port_seconds(B, H, N, D, causal):
+    """The OpenMP port (oracle/sage_oracle.c, what bench.py times live on the GPU box's cores) on the same shape and the same cores:
+    per-block scales, FP16 PV in the Triton kernels' form -- the arithmetic of the reference path timed beside it."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import oracle
+    oracle.build()
+    rng = np.random.default_rng(0)
+    q8 = rng.integers(-95, 95, (B, H, N, D), dtype=np.int8)
+    k8 = rng.integers(-95, 95, (B, H, N, D), dtype=np.int8)
+    gq, nq = oracle.group_index(N, "per_block", "q", 128, 128)
+    gk, nk = oracle.group_index(N, "per_block", "k", 64, 64)
+    qs = (0.5 + rng.random((B, H, nq))).astype(np.float32) * 0.02
+    ks = (0.5 + rng.random((B, H, nk))).astype(np.float32) * 0.02
+    v = oracle.convert(rng.standard_normal((B, H, N, D)).astype(np.float32), "f16")
+    return best_of(lambda: oracle.attn(q8, k8, v, qs, gq, ks, gk, causal=causal, c=1.0, pv_mode=oracle.PV_F16_TRITON, out_dtype=0), n=3, warm=1)
+
+
 def case(name, B, H, N, D, causal, dtype):
     g = torch.Generator().manual_seed(0)
     q = torch.randn(B, H, N, D, generator=g).to(dtype)
     k = torch.randn(B, H, N, D, generator=g).to(dtype)
     v = torch.randn(B, H, N, D, generator=g).to(dtype)
     t0 = time.perf_counter()
-    o, _, _ = ref.ref_dense(q, k, v, causal, return_lse=False)
+    o, _, _ = ref.ref_dense(q, k, v, causal, return_lse=False)       # (the interpreter is deterministic and slow: one run)
     dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    truth = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float(), is_causal=causal)
-    dt_sdpa = time.perf_counter() - t1
+    qf, kf, vf = q.float(), k.float(), v.float()
+    truth = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=causal)
+    dt_sdpa = best_of(lambda: torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=causal), n=3, warm=1)
+    dt_port = port_seconds(B, H, N, D, causal)
     cos = torch.nn.functional.cosine_similarity(o.float().flatten(), truth.flatten(), dim=0).item()
     fl = flops(B, H, N, D, causal)
     return {"case": name, "shape": {"B": B, "H": H, "N": N, "D": D, "causal": causal, "dtype": str(dtype).split(".")[-1]},
             "reference_triton_interpreter_seconds": round(dt, 2), "reference_triton_interpreter_gflops": round(fl / dt / 1e9, 4),
             "fp32_sdpa_cpu_seconds": round(dt_sdpa, 4), "fp32_sdpa_cpu_gflops": round(fl / dt_sdpa / 1e9, 2),
+            "openmp_port_seconds": round(dt_port, 4), "openmp_port_gflops": round(fl / dt_port / 1e9, 2),
+            "timing": "reference: one run; fp32 SDPA and the OpenMP port: best of 3 after one warm-up call, same cores",
             "cos_sim_vs_fp32_sdpa": round(cos, 6)}
 
 
