@@ -247,6 +247,7 @@ def test_a_pre_pass_that_gives_up_is_loud():
         assert torch.isnan(got[2]).all(), "k scales of a head that gave up must be NaN"
         assert torch.isnan(got[4]).all(), "v scales of a head that gave up must be NaN"
         assert (got[3].view(torch.uint8) == 0x7f).all(), "the V image of a head that gave up must be NaN bytes"
+        quant._PrepassGuard.of(k.device).reset()      # (the launch above set the device's host word; this test wants the fused route again)
         o = sa.sageattn(q, k, v, is_causal=False)
         torch.cuda.synchronize()
         assert torch.isnan(o.float()).all(), "attention over a poisoned pre-pass must be NaN, not a number"
