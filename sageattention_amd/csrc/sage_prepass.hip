@@ -40,6 +40,12 @@
 #ifndef SAGE_PP_TRACE
 #define SAGE_PP_TRACE 0    // experiment: thread 0 of every workgroup appends 100 MHz time stamps behind the used part of ws
 #endif
+#ifndef SAGE_PP_KWB
+#define SAGE_PP_KWB 1      // K, Triton rounding styles: the abs-max pass writes the smoothed, rounded pair back over the raw word
+#endif
+#ifndef SAGE_PP_VAMAX
+#define SAGE_PP_VAMAX 1    // V without smooth_v: statistics = abs-max on the 16-bit patterns
+#endif
 #ifndef SAGE_PP_ABL
 #define SAGE_PP_ABL 0      // experiment bits (wrong results): 1 no wait, 2 no quantise step, 4 no slab statistics
 #endif
@@ -101,7 +107,7 @@ struct PrepassLds {
 // VARLEN: k / v are packed [sum L, H, D] (sageattn_varlen, core.py:431-444): blockIdx.x is the slab's index among ALL slabs of the head
 // (sage_varlen_plan: 512-token slabs per sequence, so the 64-key scale blocks and V tiles of a sequence never straddle a slab); the
 // statistics, the barrier and the K mean span every sequence (`k.mean(dim=0)` over all packed tokens), the quantisation is per sequence.
-template <int D, int DT, bool IS_V, bool VARLEN>
+template <int D, int DT, bool IS_V, bool VARLEN, bool V_AMAX = false>
 __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<D> &lds, const int b)
 {
 
@@ -191,7 +197,28 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
         // Rows past the end read as zeros: exact for the sums.  K only needs the sums (its mean).  For V a per-row penalty
         // (0 for a row that exists, -inf otherwise) is added for the max and subtracted for the min -- two full-rate adds
         // where a select per value (v_cndmask_b32: ~22 cycles per wave on gfx950, profiles/r2_run1_ubench2.txt) cost 4x more.
-        if (!(SAGE_PP_ABL & 4)) {
+        // V without smooth_v (the default): the scale needs max |v| only -- abs-max on the 16-bit patterns (sign-magnitude formats order
+        // like unsigned integers), one v_and + one v_pk_max_u16 per PAIR instead of six fp32 operations per value; rows past the end
+        // read as zero and cannot win.  Published as (max, min) = (amax, 0): the reduction's max(|max - 0|, |min - 0|) is amax.
+        // (a template argument, chosen by the kernel's workgroup-uniform branch: as a run-time branch inside one body the two forms of
+        //  the statistics pass cost the bf16 D = 64 instantiation its third workgroup per CU -- 80 -> 93 VGPRs, 204 -> 235 us at C5)
+        if constexpr (V_AMAX) {
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            us2 am01 = {0, 0}, am23 = {0, 0};
+#pragma unroll
+            for (int i = 0; i < ((SAGE_PP_ABL & 4) ? 0 : NR); i++) {
+                const unsigned m0 = rw[i][0] & 0x7fff7fffu, m1 = rw[i][1] & 0x7fff7fffu;
+                us2 a, b;
+                __builtin_memcpy(&a, &m0, 4);
+                __builtin_memcpy(&b, &m1, 4);
+                am01 = __builtin_elementwise_max(am01, a);
+                am23 = __builtin_elementwise_max(am23, b);
+                asm volatile("" ::: "memory");              // keep the rows in order: hoisting the masks costs a register per row
+            }
+            mx[0] = ld16<DT>(am01[0]); mx[1] = ld16<DT>(am01[1]); mx[2] = ld16<DT>(am23[0]); mx[3] = ld16<DT>(am23[1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) mn[j] = 0.0f;
+        } else if (!(SAGE_PP_ABL & 4)) {
 #pragma unroll
             for (int i = 0; i < NR; i++) {
                 float pen = 0.0f;
@@ -219,9 +246,10 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 #pragma unroll
             for (int r = 0; r < RPI; r++) { a = fmaxf(a, red[0][r][tid]); c = fminf(c, red[1][r][tid]); s += red[2][r][tid]; }
             float *mine = ws + (long)gslab * 3 * D;
-            __hip_atomic_store(mine + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mine + D + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mine + 2 * D + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (what the head's reduction below reads: K the sums; V the maxima, and the minima and sums unless the abs-max suffices)
+            if constexpr (IS_V) __hip_atomic_store(mine + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (IS_V && !V_AMAX) __hip_atomic_store(mine + D + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (!V_AMAX) __hip_atomic_store(mine + 2 * D + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         SAGE_STAMP();                              // 2: slab statistics published
         // ---- 2. per-head barrier over the slabs, then the reduction in slab order (as stats_final_kernel) -------------
@@ -266,17 +294,18 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
                     const float *wi = ws + (long)min(i0 + u, nslab - 1) * 3 * D;
-                    if constexpr (IS_V) {
-                        va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vc[u] = __hip_atomic_load(wi + D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    vs[u] = __hip_atomic_load(wi + 2 * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (V with the abs-max only: one load per slab, not three -- the three cost a V workgroup 5.2 us of its 19.4 at C3 and
+                    //  17 us of 37 on heads of 64 slabs, against 0.85 / 3.2 us for K's one, profiles/r4_run_h_prepass_trace.txt)
+                    if constexpr (IS_V) va[u] = __hip_atomic_load(wi + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (IS_V && !V_AMAX) vc[u] = __hip_atomic_load(wi + D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (!V_AMAX) vs[u] = __hip_atomic_load(wi + 2 * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
                     if (i0 + u < nslab) {
-                        if constexpr (IS_V) { a = fmaxf(a, va[u]); c = fminf(c, vc[u]); }
-                        s += vs[u];
+                        if constexpr (IS_V) a = fmaxf(a, va[u]);
+                        if constexpr (IS_V && !V_AMAX) c = fminf(c, vc[u]);
+                        if constexpr (!V_AMAX) s += vs[u];
                     }
                 }
             }
@@ -289,6 +318,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 const bool smooth = p.v_mean != nullptr;
                 const float lpad = (float)((L + 15) / 16 * 16);
                 const float mean = smooth ? s / lpad : 0.0f;
+                if constexpr (V_AMAX) c = 0.0f;                      // (max, min) = (abs-max, 0)
                 if ((L & 15) != 0) { a = fmaxf(a, 0.0f); c = fminf(c, 0.0f); }
                 const float am = fmaxf(fabsf(a - mean), fabsf(c - mean));
                 ch_mean[tid] = mean;
@@ -342,6 +372,27 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             rw[i][0] |= m01 & gone;
             rw[i][1] |= m23 & gone;
         }
+#if SAGE_PP_KWB
+        // Triton rounding styles: `k - km` is rounded to the input dtype before anything else looks at it (core.py:281,
+        // quant_per_block.py:53-54), so the smoothed, rounded pair REPLACES the raw word once, here, and the two passes below run their
+        // un-smoothed forms on it (forming the pair in each pass cost 2.5 VALU instructions per element more; doing it inside the
+        // abs-max pass tipped the register allocation into 20 spilled VGPRs)
+        if (smooth && p.k_style != QS_CUDA) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    unsigned u = rw[i][c];
+                    const float lo = ld16<DT>((uint16_t)(u & 0xffffu)) - mean4[2 * c];
+                    const float hi = ld16<DT>((uint16_t)(u >> 16)) - mean4[2 * c + 1];
+                    u = pack_pair_to_dtype<DT>(lo, hi);
+                    asm volatile("" : "+v"(u));
+                    rw[i][c] = u;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+#endif
         __syncthreads();
         const int g_thread = group_of_row(r0 & (blk - 1), p.k_gran, p.k_warp);   // every row of a thread in a block: same group
         const int nblk_total = (L + blk - 1) >> bsh;
@@ -390,9 +441,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     row_values(i, f);
                     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(f[0]), fabsf(f[1]))), fmaxf(fabsf(f[2]), fabsf(f[3])));
                 } else {
-                    // values rounded to the input dtype (quant_per_block.py:53-54): the smoothed, rounded pair is formed in a
-                    // temporary (rw keeps the raw word; pass 2 recomputes the pair) and the abs-max runs on the 16-bit
-                    // patterns, which order like unsigned integers in a sign-magnitude format
+                    // values rounded to the input dtype (quant_per_block.py:53-54): the abs-max runs on the 16-bit patterns, which
+                    // order like unsigned integers in a sign-magnitude format (SAGE_PP_KWB: rw already holds the smoothed, rounded
+                    // pairs and SMOOTH is false here)
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         unsigned u = rw[i][c];
@@ -444,12 +495,11 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     float f[4];
                     row_values(i + u, f);
                     int q[4];
+                    if constexpr (STYLE == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if constexpr (STYLE == 0) q[j] = quant_round_cuda(f[j], y);
-                        else if constexpr (STYLE == 1) q[j] = quant_round_triton_nz(f[j], sc, y);
-                        else q[j] = quant_round_triton(f[j], sc, y);
-                    }
+                        for (int j = 0; j < 4; j++) q[j] = quant_round_cuda(f[j], y);
+                    } else if constexpr (STYLE == 1) quant_round_triton_nz4(f, sc, y, q);      // (the 4-wide forms of sage_quant_math.h: same bits)
+                    else quant_round_triton4(f, sc, y, q);
                     __builtin_amdgcn_raw_buffer_store_b32(pack_int8x4(q[0], q[1], q[2], q[3]), orsrc, orun, 0, SAGE_PP_NT ? 2 : 0);
                     orun += ostep;
                     asm volatile("" : "+v"(orun) :: "memory");
@@ -461,11 +511,17 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             if (smooth) quantise(style_tag, std::true_type{}); else quantise(style_tag, std::false_type{});
         };
         if (p.k_style == QS_CUDA) by_smooth(std::integral_constant<int, 0>{});
+#if SAGE_PP_KWB
+        else if (p.k_style == QS_TRITON_THREAD) quantise(std::integral_constant<int, 1>{}, std::false_type{});
+        else quantise(std::integral_constant<int, 2>{}, std::false_type{});          // QS_TRITON (the C ABI admits these three)
+#else
         else if (p.k_style == QS_TRITON_THREAD) by_smooth(std::integral_constant<int, 1>{});
         else by_smooth(std::integral_constant<int, 2>{});          // QS_TRITON (the C ABI admits these three)
+#endif
     } else {
         // ---- 3b. V: tile image, two 64-token tiles per LDS stage (the arithmetic of prep_v_kernel) ------------------------
-        const bool smooth = p.v_mean != nullptr;
+        const bool smooth = V_AMAX ? false : (p.v_mean != nullptr);      // (V_AMAX: known at compile time -- as a run-time flag the subtraction,
+                                                                             //  the row test and two v_cndmask per element stayed in the loop)
         const int ntiles = (L + BLKK - 1) / BLKK;
         constexpr int RPS = 2 * BLKK / RPI;                 // rows of a thread per stage
         auto stage_in = [&](int s) {                        // the stage's 128 rows -> LDS
@@ -567,7 +623,10 @@ template <int D, int DT, bool VARLEN>
 #ifndef SAGE_PP_WAVES      // waves per SIMD the allocator must allow (4 = two 512-thread workgroups per CU)
 #define SAGE_PP_WAVES 4
 #endif
-__global__ void __launch_bounds__(kPrepassThreads, SAGE_PP_WAVES)
+#ifndef SAGE_PP_WAVES64    // D = 64 holds half the data registers: three workgroups per CU (<= 85 VGPRs).  Left to the default bound the bf16
+#define SAGE_PP_WAVES64 6  // instantiation drifted from 80 to 93 VGPRs with a source change and lost the third workgroup: 204 -> 235 us at C5
+#endif
+__global__ void __launch_bounds__(kPrepassThreads, (D == 64 ? SAGE_PP_WAVES64 : SAGE_PP_WAVES))
 prepass_kv_kernel(const PrepassParams p)
 {
     __shared__ PrepassLds<D> lds;
@@ -575,8 +634,10 @@ prepass_kv_kernel(const PrepassParams p)
     // measured the same at C3 and 15 % slower at B=16 H=32 N=1024)
     const int is_v = (p.parts == 3) ? (int)(blockIdx.z & 1) : (p.parts == 2);
     const int b = (p.parts == 3) ? (int)(blockIdx.z >> 1) : (int)blockIdx.z;
-    if (is_v) prepass_body<D, DT, true, VARLEN>(p, lds, b);
-    else prepass_body<D, DT, false, VARLEN>(p, lds, b);
+    if (is_v) {
+        if (SAGE_PP_VAMAX && !VARLEN && p.v_mean == nullptr && p.v_fp16 == 0) prepass_body<D, DT, true, VARLEN, true>(p, lds, b);
+        else prepass_body<D, DT, true, VARLEN>(p, lds, b);
+    } else prepass_body<D, DT, false, VARLEN>(p, lds, b);
 }
 
 __global__ void __launch_bounds__(256) prepass_zero_sync_kernel(unsigned *sync, int words)

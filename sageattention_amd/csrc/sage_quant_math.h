@@ -52,6 +52,39 @@ __device__ __forceinline__ int quant_round_triton_nz(float x, float sc, float y)
     return (int)t;
 }
 
+// Four elements of one scale group at a time, the same operations on 4-wide vectors: the compiler emits v_pk_mul_f32 / v_pk_fma_f32 and
+// the four dependent chains (mul, 4 x fma, +-0.5, convert) advance in lock-step, two independent packed instructions per step, instead
+// of one element's eight-instruction chain after the other (what it schedules for the scalar form when it is saving registers).
+typedef float sage_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sage_f4 quant_quotient4(const sage_f4 x, float sc, float y)
+{
+    const sage_f4 ys = {y, y, y, y}, ns = {-sc, -sc, -sc, -sc};
+    sage_f4 t = x * ys;
+    t = __builtin_elementwise_fma(__builtin_elementwise_fma(ns, t, x), ys, t);
+    t = __builtin_elementwise_fma(__builtin_elementwise_fma(ns, t, x), ys, t);
+    return t;
+}
+__device__ __forceinline__ void quant_round_triton_nz4(const float (&x)[4], float sc, float y, int (&q)[4])
+{
+    sage_f4 t = quant_quotient4(sage_f4{x[0], x[1], x[2], x[3]}, sc, y);
+    const sage_f4 h = {__builtin_copysignf(0.5f, t[0]), __builtin_copysignf(0.5f, t[1]), __builtin_copysignf(0.5f, t[2]), __builtin_copysignf(0.5f, t[3])};
+    t += h;
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = (int)t[j];
+}
+__device__ __forceinline__ void quant_round_triton4(const float (&x)[4], float sc, float y, int (&q)[4])
+{
+    sage_f4 t = quant_quotient4(sage_f4{x[0], x[1], x[2], x[3]}, sc, y);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float u = t[j];
+        u += (u >= 0.0f) ? 0.5f : -0.5f;
+        int qi = (int)u;
+        qi = qi > 127 ? 127 : (qi < -128 ? -128 : qi);
+        q[j] = (sc == 0.0f) ? 0 : qi;
+    }
+}
+
 // four INT8 lanes of one dword from four integers in [-128, 127]: three v_perm_b32 / v_or
 __device__ __forceinline__ unsigned pack_int8x4(int q0, int q1, int q2, int q3)
 {

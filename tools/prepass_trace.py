@@ -32,7 +32,7 @@ vs = torch.empty(B, H, D, dtype=torch.float32, device=dev)
 def run():
     rc = lib.sage_prepass_kv(k.data_ptr(), v.data_ptr(), km.data_ptr(), k8.data_ptr(), ks.data_ptr(), vi.data_ptr(), vs.data_ptr(), None,
                              ws.data_ptr(), sync.data_ptr(), B, H, L, D, *k.stride()[:3], *v.stride()[:3], *k8.stride()[:3],
-                             64, _cabi.GRAN_PER_THREAD, _cabi.QSTYLE_TRITON_THREAD, 448.0, _cabi.DTYPE_BF16,
+                             64, _cabi.GRAN_PER_THREAD, _cabi.QSTYLE_TRITON_THREAD, 448.0, 0, _cabi.DTYPE_BF16, None,
                              torch.cuda.current_stream().cuda_stream)
     _cabi.check(rc, "sage_prepass_kv")
 for _ in range(3):
