@@ -74,13 +74,15 @@ CONFIGS = {
 # instruction the PV step issues; the non-scaled fp8 MFMA runs at the bf16 rate), int8 = 2x bf16 = 5.0 POPS.
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
-# HBM bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-# gfx950 correction per MI355X_MICROARCH.md).  c3 / c2: profiles/r3_run_k_order_traffic.txt (FETCH_SIZE / WRITE_SIZE are in KiB: c3 = (2 x 147446 +
-# 131072) KiB, c2 = (2 x 111159 + 65536) KiB with the round-3 causal work order, whose groups of heads share an XCD's L2: round 2's head-major
-# order moved 350.2e6 / 205.2e6 and was 5-15 % slower); c5 (non-causal, order unchanged): profiles/r2_run_m_pmc_c5.txt
-PMC_TRAFFIC_BYTES = {"c3": 436.2e6, "c5": 602.4e6, "c2": 294.8e6}
-ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6}
-PMC_NOTE = "HBM bytes per launch from committed rocprofv3 PMC passes (profiles/r3_run_k_order_traffic.txt, r2_run_m_pmc_c5.txt)"
+# HBM-side bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KiB, gfx950 correction per
+# MI355X_MICROARCH.md; FETCH_SIZE counts what the L2s request from the fabric, Infinity-Cache hits included), round 4,
+# profiles/r4_run_j_pmc_traffic.txt: c3 (2 x 147603 + 131072) KiB, c2 (2 x 106764 + 65536) KiB -- the causal work order's groups of heads share an
+# XCD's L2 (round 2's head-major order moved 350.2e6 / 205.2e6 and was 5-15 % slower); c4 causal (2 x 549754 + 268096) KiB, non-causal
+# (2 x 609647 + 268096) KiB: K + V of one kv-head of the 16384-token sequence are 6.3 MB against a 4 MB L2; c5 (non-causal): profiles/r2_run_m_pmc_c5.txt
+PMC_TRAFFIC_BYTES = {"c3": 436.5e6, "c5": 602.4e6, "c2": 285.8e6, "c4": 1400.4e6, "c4nc": 1523.1e6}
+# algorithmic bytes: INT8 q (kernel-only bench) + 16-bit o + INT8 k + FP8 / FP16 V image; c4: 16-bit q (quantised in the prologue) + o + k + fp16 V
+ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6, "c4": 651.9e6, "c4nc": 651.9e6}
+PMC_NOTE = "L2-miss bytes per launch from committed rocprofv3 PMC passes (profiles/r4_run_j_pmc_traffic.txt, r2_run_m_pmc_c5.txt)"
 
 
 def blended_peak(pv: str) -> float:
@@ -370,7 +372,8 @@ def measure_c4(steps, warmup, ramp, device):
         wall, _ = timed(fn, steps, max(2, warmup // 2), False, ramp)
         out["causal" if causal else "non_causal"] = {
             "kernel_only": {"ms_per_launch": round(kern_ms, 4), "tflops": round(fl / kern_ms / 1e9, 2)},
-            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (packed / varlen launch over the device-built work list)"),
+            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (packed / varlen launch over the device-built work list)",
+                                     "c4" if causal else "c4nc"),
             "end_to_end": {"ms_per_call": round(wall / steps * 1e3, 4), "tflops": round(fl / (wall / steps) / 1e12, 2),
                            "what": "sageattn_varlen(): plan launch + one-launch K/V pre-pass + attention"}}
         del st

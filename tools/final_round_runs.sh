@@ -1,12 +1,21 @@
 #!/bin/bash
-# The record of a round's last commit: bench lines of every configuration, rocprofv3 kernel stats of the default workload, PMC passes of its kernel.
-# usage (on the GPU box): TAG=r3p bash tools/final_round_runs.sh
+# The record of a round's last commit: the default bench line (every configuration), the other bench lines, rocprofv3 kernel-trace summaries per
+# configuration (c3 headline, c2, c4, c5) and the HBM-traffic PMC passes of the attention kernel (c3, c2, c4).
+# usage (on the GPU box): TAG=r4z bash tools/final_round_runs.sh
 tag="${TAG:-final}"; out="gpurun_out/$tag"; mkdir -p "$out"
-export SAGE_ATTN64=0
-timeout 300 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 400 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
 for c in c2 c5 c3nc n32k c4; do timeout 200 python bench.py --config $c --no-cpu-baseline > "$out/bench_$c.json" 2> "$out/bench_$c.err"; done
-TAG=$tag bash tools/gpucall.sh prof --no-sweep --no-cpu-baseline > /dev/null 2>&1
-TAG=$tag bash tools/gpucall.sh pmc c3 0 > /dev/null 2>&1
-TAG=$tag bash tools/gpucall.sh pmc c2 0 > /dev/null 2>&1
+prof() {   # name, bench.py args: rocprofv3 --kernel-trace --stats summary of one bench.py run
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$1" -- python bench.py "${@:2}" > "$out/bench_under_rocprof_$1.json" 2> "$out/bench_under_rocprof_$1.err"
+  f=$(ls "$out"/prof_$1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" "$out/kernel_stats_$1.csv"; rm -rf "$out/prof_$1"
+  echo "== $1: $(cut -c1-200 "$out/bench_under_rocprof_$1.json")"; head -5 "$out/kernel_stats_$1.csv" | cut -c1-200
+}
+prof c3 --no-sweep --no-configs --no-cpu-baseline
+prof c2 --config c2 --no-cpu-baseline
+prof c4 --config c4
+prof c5 --config c5 --no-cpu-baseline
+for c in c3 c2 c4 c4nc; do
+  echo "== traffic $c"; SAGE_PMC_CFG=$c bash tools/pmc_passes.sh "$out/pmc_tmp" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" 2>&1 | tee "$out/pmc_traffic_$c.txt"
+done
 for f in "$out"/bench_*.json; do echo "$f: $(cut -c1-160 $f)"; done
-head -6 "$out/kernel_stats.csv"

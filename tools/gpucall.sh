@@ -5,13 +5,13 @@
 #   tests [pytest args]          python -m pytest tests -m gpu -q [args]          -> gpurun_out/<tag>/gpu_suite.log, parity_report.json
 #   bench [bench.py args]        python bench.py [args]                            -> gpurun_out/<tag>/bench.json
 #   prof  [bench.py args]        rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/<tag>/kernel_stats.csv, bench_under_rocprof.json
-#   pmc   <cfg> [mode]           PMC passes over the attention kernel only (tools/run_kernel.py <cfg>); mode = SAGE_ATTN64 value
+#   pmc   <cfg>                  PMC passes over the attention kernel only (tools/run_kernel.py <cfg>; cfg may be c4 / c4nc)
 #   pmcpp                        PMC passes over the one-launch pre-pass at the C3 shape (FETCH_SIZE / WRITE_SIZE / SQ)
 #   ab    <cfg> tag1 tag2 ...    tools/variant_bench.py over libraries built by tools/build_variants.sh
-# env: TAG (output directory under gpurun_out/, default r3), SAGE_ATTN64 (attention route for bench / ab / pmc)
+# env: TAG (output directory under gpurun_out/, default r4)
 set -u
 task="${1:-}"; shift || true
-tag="${TAG:-r3}"
+tag="${TAG:-r4}"
 out="gpurun_out/$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -31,9 +31,9 @@ case "$task" in
     f=$(ls "$out"/prof/*/*kernel_stats.csv | head -1); cp "$f" "$out/kernel_stats.csv"; head -8 "$out/kernel_stats.csv"; rm -rf "$out/prof"
     cut -c1-600 "$out/bench_under_rocprof.json" ;;
   pmc)
-    cfg="${1:-c3}"; mode="${2:-${SAGE_ATTN64:--1}}"
-    SAGE_ATTN64=$mode SAGE_PMC_CFG=$cfg bash tools/pmc_passes.sh "$out/pmc_${cfg}_mode$mode" "${ATTN_CTRS[@]}" > "$out/pmc_${cfg}_mode$mode.txt" 2>&1
-    cat "$out/pmc_${cfg}_mode$mode.txt" ;;
+    cfg="${1:-c3}"
+    SAGE_PMC_CFG=$cfg bash tools/pmc_passes.sh "$out/pmc_${cfg}" "${ATTN_CTRS[@]}" > "$out/pmc_${cfg}.txt" 2>&1
+    cat "$out/pmc_${cfg}.txt" ;;
   pmcpp)
     bash tools/pmc_prepass.sh "$out/pmc_prepass" 2>&1 | tee "$out/pmc_prepass.txt" ;;
   ab)

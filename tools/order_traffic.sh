@@ -6,5 +6,5 @@ cfg="$1"; shift
 for spec in "$@"; do
   g="${spec%%:*}"; t=""; [ "$spec" != "$g" ] && t="${spec#*:}"
   echo "== $cfg SAGE_ORDER_GROUP=$g SAGE_ORDER_TAILG=$t"
-  SAGE_ATTN64=0 SAGE_ORDER_GROUP=$g SAGE_ORDER_TAILG=$t SAGE_PMC_CFG=$cfg bash tools/pmc_passes.sh gpurun_out/order_traffic_tmp "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"
+  SAGE_ORDER_GROUP=$g SAGE_ORDER_TAILG=$t SAGE_PMC_CFG=$cfg bash tools/pmc_passes.sh gpurun_out/order_traffic_tmp "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"
 done

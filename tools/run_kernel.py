@@ -10,9 +10,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
+if name in ("c4", "c4nc"):        # BASELINE.json configs[3]: the attention launch of sageattn_varlen on the operands its pre-pass produced
+    from sageattention_amd import core
+    g = torch.Generator(device="cpu").manual_seed(4)
+    total = sum(bench.C4_LENS)
+    q = torch.randn(total, 32, 128, generator=g).to(torch.bfloat16).to(dev)
+    k = torch.randn(total, 8, 128, generator=g).to(torch.bfloat16).to(dev)
+    v = torch.randn(total, 8, 128, generator=g).to(torch.bfloat16).to(dev)
+    cu = torch.tensor([0] + list(torch.tensor(bench.C4_LENS).cumsum(0)), dtype=torch.int32, device=dev)
+    st = core._varlen_prepare(q, k, v, cu, cu, max(bench.C4_LENS), max(bench.C4_LENS), name == "c4", None, True, {})
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        core._varlen_attend(st)
+    torch.cuda.synchronize()
+    print("done")
+    sys.exit(0)
+cfg = bench.CONFIGS[name]
 q, k, v = bench.make_inputs(cfg, dev, 1234)
 ops = bench.prequantize(cfg, q, k, v)
 torch.cuda.synchronize()
