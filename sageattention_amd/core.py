@@ -507,9 +507,11 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
                                   qk_quant_gran: str = "per_thread", sm_scale: Optional[float] = None,
                                   pv_accum_dtype: str = "fp32", smooth_k: bool = True, smooth_v: bool = False,
                                   return_lse: bool = False, **kwargs: Any):
-    """INT8 QK^T + FP16 PV (reference core.py:451-633).  ``pv_accum_dtype`` "fp32" accumulates
-    straight into FP32; "fp16+fp32" keeps the reference's per-tile buffer structure (the tile
-    buffer is FP32 here: CDNA4 MFMA has no FP16 accumulator); "fp16" maps to "fp32"."""
+    """INT8 QK^T + FP16 PV (reference core.py:451-633).  All three ``pv_accum_dtype`` values run the same arithmetic here: P.V is
+    accumulated in FP32 (CDNA4's FP16 MFMA has no FP16 accumulator, so the reference's FP16 accumulator and its FP16 tile buffer
+    have no counterpart) and the softmax denominator sums the fp16-ROUNDED probabilities in FP32, as the reference's tensor-core row
+    sum does in every instantiation (qk_int_sv_f16_cuda_sm80.cu:313-320).  "fp16+fp32" differs from "fp32" only in the q scale groups
+    the reference pairs with it (WARPQ = 16 at head_dim 128, core.py:602-604); "fp16" additionally honours ``smooth_v``."""
     if torch.compiler.is_compiling():
         return _compiled_call("fp16", q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse, kwargs)
     dtype = q.dtype
