@@ -273,6 +273,14 @@ def timed(fn, steps, warmup, dist_on, ramp_s=0.0):
     return wall, dev_ms
 
 
+def _median(xs):
+    """Median launch duration of a sweep point (20 launches): one stray multi-millisecond launch -- seen once in this round's runs, N = 4096
+    at 224 instead of ~1400 TFLOP/s by the mean -- must not decide a point of the curve.  The headline and the `roofline` objects keep the
+    mean the contract asks for."""
+    ys = sorted(xs)
+    return ys[len(ys) // 2] if len(ys) % 2 else 0.5 * (ys[len(ys) // 2 - 1] + ys[len(ys) // 2])
+
+
 def roofline_obj(fl, kern_ms, pv, kernel, config_name=None):
     achieved = fl / (kern_ms * 1e-3) / 1e12
     peak = blended_peak(pv)
@@ -469,7 +477,7 @@ def other_configs(args, device):
     del q, k, v
     # the reference bench script's own shape: batch 4, per_warp (sm90 groups), N = 1k .. 32k, causal and non-causal, kernel-only
     sw = {"what": "kernel-only TFLOP/s, batch 4, H=32, D=128, qk_quant_gran per_warp in the sm90 kernels' groups (q per 16 rows, k per 128 keys), "
-                  "fp32+fp32 -- bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7-11,33-50; 20 launches each, HIP events",
+                  "fp32+fp32 -- bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7-11,33-50; median of 20 launches each (10 at N = 32k), HIP events",
           "h100_published_causal": {"1024": 448, "2048": 624, "4096": 744, "8192": 795, "16384": 835, "32768": 858}}
     for causal in (True, False):
         row = {}
@@ -479,7 +487,7 @@ def other_configs(args, device):
             oo = prequantize(c, qq, kk, vv)
             del qq, kk, vv
             _, d = timed(lambda: kernel_only_step(c, oo), 20 if n <= 16384 else 10, 5, False, ramp)
-            row[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
+            row[str(n)] = round(flops(c) / (_median(d) * 1e-3) / 1e12, 1)
             del oo
         sw["causal" if causal else "non_causal"] = row
     out["sweep_b4_per_warp"] = sw
@@ -660,10 +668,10 @@ def main():
                     qq, kk, vv = make_inputs(c, device, 99)
                     oo = prequantize(c, qq, kk, vv)
                     _, d = timed(lambda: kernel_only_step(c, oo, sm_scale), 20, 5, False, min(args.ramp_seconds, 0.2))
-                    sweep[str(n)] = round(flops(c) / (sum(d) / len(d) * 1e-3) / 1e12, 1)
+                    sweep[str(n)] = round(flops(c) / (_median(d) * 1e-3) / 1e12, 1)
                     del qq, kk, vv, oo
                 out[key] = sweep
-            out["sweep_note"] = ("kernel-only TFLOP/s of the workload's kernel at N = 1k .. 32k (B=%d, H=%d, D=%d, %s): 20 launches each, HIP events"
+            out["sweep_note"] = ("kernel-only TFLOP/s of the workload's kernel at N = 1k .. 32k (B=%d, H=%d, D=%d, %s): median of 20 launches each, HIP events"
                                  % (cfg["B_global"], CONFIGS[args.config]["H"], cfg["D"], "causal" if cfg["causal"] else "non-causal"))
         if args.config == "c3" and world == 1 and not args.no_configs:
             del q, k, v, ops

@@ -190,21 +190,20 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
  *   sync  sage_prepass_sync_words(B,H) uint32 of scratch, private to the call while it runs (it need not be initialised: the
  *         entry point zeroes it on `stream` before the launch).  Layout: 32 words per (K|V, b, h):
- *         [0] arrivals, [1] departures, [2] give-up flag: set if a workgroup waited ~1 s for the other slabs of its head in
- *         vain (the co-residency assumption below was violated).  Giving up is loud: such a workgroup, and every workgroup
- *         of the head that leaves the wait after it, writes NaN scales (K) / NaN image bytes and a NaN v_scale (V), so the
- *         attention call that consumes the pre-pass returns NaN for the affected head instead of a plausible wrong number.
- *         sage_prepass_failed_heads(sync, B, H, stream) synchronises the stream and returns how many (K|V, b, h) entries
- *         carry the flag (0 = the launch was sound).
+ *         [0] arrivals, [1] departures, [2] give-up flag: set if a workgroup waited tens of milliseconds for the other slabs of its
+ *         head in vain (the co-residency assumption below was violated).  Such a workgroup computes the head's statistics itself --
+ *         it re-reads the whole head, slab by slab, through the same summation order -- so the outputs are the same bits as ever; the
+ *         launch is slow, not wrong (rounds 2-3 wrote NaN instead).  sage_prepass_failed_heads(sync, B, H, stream) synchronises the
+ *         stream and returns how many (K|V, b, h) entries carry the flag (0 = nobody had to).
  *   L     at most sage_prepass_max_seqlen() (65536 on a whole MI355X; 512 x the CU count on a smaller partition): the slabs of a
  *         head wait for each other inside the launch, so all of them must fit on the device at once; longer
  *         sequences take the three-call sequence (SAGE_EINVAL here).  The bound uses the compute units `stream` may use
  *         (hipExtStreamGetCUMask): sage_prepass_max_seqlen_stream(stream) is that bound.  Per head, ((ceil(L/512)*512 - 1) * row
  *         stride + D) * 2 must stay below 2^32.
  *   host_flag  nullable: a device-visible pinned HOST word (hipHostMalloc).  A workgroup that gives up also stores 1 there
- *         (system scope), so the caller can notice a poisoned launch at its next call without synchronising -- the Python layer
+ *         (system scope), so the caller can notice a slow launch at its next call without synchronising -- the Python layer
  *         then warns and routes the device's later calls through the three-call sequence.  What the bound above cannot see is
- *         compute units held by OTHER streams' kernels (e.g. RCCL) for longer than the ~1 s wait.
+ *         compute units held by OTHER streams' kernels (e.g. RCCL) for longer than the wait.
  */
 /* K-smoothing mean of a packed batch x[sum L, H, D] over ALL tokens (core.py:432-434) -> mean_out [H, D], summed over the per-sequence
  * 512-token slabs of sage_varlen_plan (slab_first / slab_seq / hdr) -- the partition, hence the bits, of sage_prepass_kv_varlen.
@@ -222,7 +221,7 @@ SAGE_API int sage_host_word_alloc(void **host_ptr, void **device_ptr);
 SAGE_API int sage_host_word_free(void *host_ptr);
 SAGE_API int sage_prepass_failed_heads(const uint32_t *sync, int B, int H, void *stream);
 /* test hook: non-zero makes every following sage_prepass_kv launch wait for a slab that does not exist and give up after
- * 2^10 polls, i.e. exercises the give-up path above (process-wide; reset with 0) */
+ * 2^10 polls, i.e. every workgroup takes the recompute path above (process-wide; reset with 0) */
 SAGE_API void sage_debug_prepass_fail(int on);
 SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale,
                     void *v_image, float *v_scale, float *v_mean, float *ws, uint32_t *sync,
@@ -240,7 +239,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
  * from sage_varlen_plan.  nslab_bound = the host-known bound ceil(total_tokens / 512) + nseq sizes the grid and the workspace
  * (ws: 2 * H * nslab_bound * 3 * D floats = sage_prepass_ws_floats(1, H, 512 * nslab_bound, D); sync: sage_prepass_sync_words(1, H)).
  * With k_mean the slabs of a head -- all sequences -- wait for each other inside the launch: nslab_bound must not exceed 128 nor the compute
- * units `stream` may use (SAGE_EINVAL otherwise: take the three-call sequence).  Giving up is loud as for sage_prepass_kv (NaN k scales). */
+ * units `stream` may use (SAGE_EINVAL otherwise: take the three-call sequence).  A workgroup that gives up recomputes, as in sage_prepass_kv. */
 SAGE_API int sage_prepass_kv_varlen(const void *k, const void *v, void *k_mean, int8_t *k_int8, float *k_scale, void *v_image,
                                     float *ws, uint32_t *sync, const int32_t *cu_seqlens_k, const int32_t *cu_k_scale,
                                     const int32_t *slab_first, const int32_t *slab_seq, const int32_t *hdr,

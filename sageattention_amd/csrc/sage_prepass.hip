@@ -19,12 +19,13 @@
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.
 // The two counters of a head return to zero before the kernel ends, so one zero-initialised sync buffer serves every
-// call issued in stream order (the C ABI zeroes the buffer before every launch all the same: a launch that gave up must
-// not poison the next one).  The wait is bounded: after ~1 s a workgroup gives up and sets word 2 of the head's sync line.
-// Giving up is LOUD: every workgroup that leaves the wait with that word set -- the one that gave up, and any that arrive
-// later -- poisons what it writes (K: NaN scales for its blocks; V: NaN bytes in its image tiles, NaN v_scale), so the
-// attention kernel that consumes the pre-pass returns NaN for every query that attends to the affected keys instead of a
-// plausible wrong number; sage_prepass_failed_heads() reads the flags back for a host-side check.
+// call issued in stream order (the C ABI zeroes the buffer before every launch all the same).  The wait is bounded (tens of
+// milliseconds) and the assumption is not load-bearing for correctness: a workgroup whose head-mates have not all arrived in time sets
+// word 2 of the head's sync line (and the caller's pinned host word), then computes the head's statistics ITSELF -- it streams the whole
+// head through a rolled copy of the statistics pass, slab by slab in index order, which reproduces every slab's partial bit for bit --
+// and carries on.  The launch is then slow (nslab x the read traffic for that workgroup), never wrong: rounds 2-3 poisoned the outputs
+// with NaN instead.  sage_prepass_failed_heads() reads the flags back; the Python layer routes the device's later calls through the kernel
+// sequence once its host word is set (a performance decision, quant._PrepassGuard).
 #include "sage_common.h"
 #include "sage_kernels.h"
 #include "sage_quant_math.h"
@@ -127,7 +128,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     constexpr int LDT = D + 8;
     auto &red = lds.red; auto &tile = lds.tile; auto &ch_mean = lds.ch_mean; auto &ch_recp = lds.ch_recp;
     auto &kmean = lds.kmean; auto &gmax = lds.gmax; auto &gsc = lds.gsc; auto &gy = lds.gy;
-    bool failed = false;                        // this workgroup's statistics cannot be trusted: poison what it writes
+    bool failed = false;                        // this workgroup stopped waiting for its head-mates: it computes the head's statistics itself
     constexpr int is_v = IS_V ? 1 : 0;
 
     const int tid = threadIdx.x;
@@ -234,7 +235,9 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     sm[2 * c] += lo;
                     sm[2 * c + 1] += hi;
                 }
-                asm volatile("" ::: "memory");
+                // the rows stay in order (a "memory" clobber does not order register arithmetic; tying the accumulators does): the
+                // compiler otherwise unpacks several rows ahead, and at D = 64 (80 VGPRs for three workgroups per CU) that is a spill
+                asm volatile("" : "+v"(sm[0]), "+v"(sm[1]), "+v"(sm[2]), "+v"(sm[3]) :: "memory");
             }
         }
 #pragma unroll
@@ -264,30 +267,89 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(cnt, 1u, SAGE_PP_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // bounded (about a second): if the forward-progress assumption above were ever violated the launch would
-                // finish with NaN-poisoned outputs and a flag in the head's sync line instead of hanging the device
+                // bounded (tens of milliseconds): if the forward-progress assumption above is violated -- compute units held by another
+                // stream's kernels -- this workgroup stops waiting, records it (word 2 of the head's sync line, the caller's host word) and
+                // computes the head's statistics ITSELF below; nothing it writes depends on another workgroup then
                 const unsigned want = (unsigned)nslab + (p.debug_fail ? 1u : 0u);
-                const unsigned bound = p.debug_fail ? (1u << 10) : (1u << 20);
-                unsigned polls = 0;
+                const unsigned bound = p.debug_fail ? (1u << 10) : (1u << 15);
+                unsigned polls = 0, gave_up = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++polls > bound) {
                         __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (p.host_flag != nullptr) __hip_atomic_store(p.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        gave_up = 1;
                         break;
                     }
                 }
-                // a workgroup that arrives after another one gave up finds the count complete -- and the flag set
-                lds.failed = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lds.failed = gave_up;      // (a workgroup that arrives after another one gave up finds the count complete: the partials are all there)
             }
             __syncthreads();
             failed = lds.failed != 0;
         }
         SAGE_STAMP();                              // 3: every slab of the head has arrived
-        if (tid < D) {
+        float a = -INFINITY, c = INFINITY, s = 0.0f;
+        if (failed) {
+            // The head's other slabs did not all arrive in time.  Stream the whole head (every sequence's slabs of this kv head when packed)
+            // through a rolled, register-light copy of the statistics pass, slab by slab in index order: each slab's partial is bit for bit
+            // the one its own workgroup publishes (a thread's rows in index order, the threads of a channel in row order, the slabs in
+            // index order), so the result does not depend on who computed it.  nslab x the read traffic of a workgroup, on a path that
+            // would otherwise have produced garbage; the slab in rw is untouched.
+            for (int i = 0; i < nslab; i++) {
+                const uint16_t *xi = x;
+                int Li = L, si = i;
+                if constexpr (VARLEN) {
+                    typedef const __attribute__((address_space(4))) int *cint_p;
+                    const int seq = ((cint_p)p.slab_seq)[i];
+                    si = i - ((cint_p)p.slab_first)[seq];
+                    const long t0 = ((cint_p)p.cu)[seq];
+                    Li = ((cint_p)p.cu)[seq + 1] - (int)t0;
+                    xi = x + (t0 - tok0) * x_sl;
+                }
+                const int rbeg = si * kStatsSlab + r0, rend = min(Li, si * kStatsSlab + kStatsSlab);
+                float fx[4], fn[4], fs[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { fx[j] = V_AMAX ? 0.0f : -INFINITY; fn[j] = V_AMAX ? 0.0f : INFINITY; fs[j] = 0.0f; }
+                const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(xi), 0,
+                                                                                      (unsigned)(((long)(Li - 1) * x_sl + D) * 2), 0x00020000);
+                unsigned vo = (unsigned)(rbeg * (int)x_sl + c4) * 2u;
+#pragma nounroll
+                for (int r = rbeg; r < rend; r += RPI) {
+                    const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rs_i, vo, 0, 0);
+                    vo += (unsigned)(RPI * (int)x_sl) * 2u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const unsigned w = t[j >> 1];
+                        const float f = ld16<DT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+                        if constexpr (V_AMAX) fx[j] = fmaxf(fx[j], fabsf(f));
+                        else if constexpr (IS_V) { fx[j] = fmaxf(fx[j], f); fn[j] = fminf(fn[j], f); fs[j] += f; }
+                        else fs[j] += f;                     // (K: the mean needs the sums only)
+                    }
+                }
+                __syncthreads();                     // (the LDS scratch of the previous slab's reduction is free again)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if constexpr (IS_V) red[0][r0][c4 + j] = fx[j];
+                    if constexpr (IS_V && !V_AMAX) red[1][r0][c4 + j] = fn[j];
+                    if constexpr (!V_AMAX) red[2][r0][c4 + j] = fs[j];
+                }
+                __syncthreads();
+                if (tid < D) {
+                    float ai = -INFINITY, ci = INFINITY, s_i = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < RPI; r++) {
+                        if constexpr (IS_V) ai = fmaxf(ai, red[0][r][tid]);
+                        if constexpr (IS_V && !V_AMAX) ci = fminf(ci, red[1][r][tid]);
+                        if constexpr (!V_AMAX) s_i += red[2][r][tid];
+                    }
+                    if constexpr (IS_V) a = fmaxf(a, ai);
+                    if constexpr (IS_V && !V_AMAX) c = fminf(c, ci);
+                    if constexpr (!V_AMAX) s += s_i;
+                }
+            }
+        } else if (tid < D) {
             // slabs in index order; sixteen slabs' loads are in flight together (one round trip to the coherence point per batch,
             // not one per slab: with the loads issued one by one this loop alone cost ~2 us x nslab per workgroup)
-            float a = -INFINITY, c = INFINITY, s = 0.0f;
             constexpr int NB = (D == 128) ? 16 : 8;       // slabs per batch of loads (D = 64: 8 keeps the kernel at 3 workgroups per CU)
             for (int i0 = 0; i0 < nslab; i0 += NB) {
                 float va[NB], vc[NB], vs[NB];
@@ -309,6 +371,8 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     }
                 }
             }
+        }
+        if (tid < D) {
             if constexpr (!IS_V) {
                 const uint16_t m = st16<DT>(s / (float)(VARLEN ? p.L : L));      // k.mean(dim=seq) in the input dtype, one rounding (VARLEN: over all packed tokens)
                 kmean[tid] = m;
@@ -324,7 +388,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 ch_mean[tid] = mean;
                 ch_recp[tid] = am > 0.0f ? p.scale_max / am : 0.0f;
                 if (gslab == 0) {
-                    p.v_scale[bh * D + tid] = failed ? __uint_as_float(0x7fc00000u) : am / p.scale_max;
+                    p.v_scale[bh * D + tid] = am / p.scale_max;
                     if (smooth) p.v_mean[bh * D + tid] = mean;
                 }
             }
@@ -483,7 +547,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 gy[kb][g] = (STYLE == 0) ? 127.0f / am : quant_recip(sc);       // fused.cu:164
                 float *ksc_out = VARLEN ? p.k_scale + (tile0 + gb) * p.H + h                   // [sum nblk, H] (quant_per_block_varlen.py:75-76)
                                         : p.k_scale + (bh * nblk_total + gb) * ngroups + g;
-                if (gb < nblk_total) *ksc_out = failed ? __uint_as_float(0x7fc00000u) : sc;
+                if (gb < nblk_total) *ksc_out = sc;
             }
             __syncthreads();
             unsigned orun = ooff;
@@ -562,7 +626,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                         for (int w = 0; w < 4; w++) {
                             int word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
                             word = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], word, true);
-                            pk[w] = failed ? 0x7f7f7f7fu : (unsigned)word;       // 0x7f: e4m3fn NaN
+                            pk[w] = (unsigned)word;
                         }
                         if constexpr (SAGE_PP_NT != 0) __builtin_nontemporal_store(pk, reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16));
                         else *reinterpret_cast<v4u *>(img + (long)t * (D * 64) + d * 64 + pc * 16) = pk;

@@ -308,8 +308,9 @@ def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
 
 
 def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
-    """Synchronise and count the (K|V, batch, head) entries of a pre-pass call whose workgroups gave up waiting for each other
-    (their outputs are NaN-poisoned; 0 = sound).  Debugging / test aid: ``SAGE_DEBUG=1`` makes ``prepass_kv_fp8`` call it."""
+    """Synchronise and count the (K|V, batch, head) entries of a pre-pass call in which a workgroup stopped waiting for its head-mates and
+    computed the head's statistics itself (the outputs are right; 0 = nobody had to).  Debugging / test aid: ``SAGE_DEBUG=1`` makes
+    ``prepass_kv_fp8`` call it and warn."""
     n = int(_cabi.load().sage_prepass_failed_heads(_p(sync), B, H, _stream(sync)))
     if n < 0:
         _cabi.check(n, "sage_prepass_failed_heads")
@@ -317,12 +318,12 @@ def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
 
 
 class _PrepassGuard:
-    """Per-device watch on the one-launch pre-pass's in-launch head barrier.  The barrier needs every slab of a head resident at once; the
+    """Per-device watch on the one-launch pre-pass's in-launch head barrier.  The barrier wants every slab of a head resident at once; the
     C ABI bounds that by the compute units the launch stream may use, but it cannot see compute units that OTHER streams' kernels hold
-    (an RCCL kernel beside the attention stream).  A workgroup that waits in vain (~1 s) poisons its outputs with NaN and stores 1 into
-    this guard's pinned host word (``host_flag`` of ``sage_prepass_kv``).  The word is read -- a plain host memory read, no
-    synchronisation -- at the start of every later pre-pass on the device: once it is set the device's calls take the three-call sequence
-    for the rest of the process and a warning says that an earlier call returned NaN-poisoned output."""
+    (an RCCL kernel beside the attention stream).  A workgroup that waits in vain (tens of milliseconds) computes the head's statistics
+    itself -- the result is still right, the launch is slow -- and stores 1 into this guard's pinned host word (``host_flag`` of
+    ``sage_prepass_kv``).  The word is read -- a plain host memory read, no synchronisation -- at the start of every later pre-pass on the
+    device: once it is set the device's calls take the kernel sequence for the rest of the process (a warning says so once)."""
     _by_device: dict = {}
 
     def __init__(self, device: torch.device):
@@ -344,9 +345,9 @@ class _PrepassGuard:
     def fused_allowed(self) -> bool:
         if not self.tripped and ctypes.c_int32.from_address(self.host).value != 0:
             self.tripped = True
-            warnings.warn(f"sageattention_amd: a one-launch K/V pre-pass on {self.device} gave up waiting for the other slabs of a head "
-                          "(compute units held by another stream?); the attention output of that call is NaN-poisoned.  This device's "
-                          "calls take the kernel sequence from now on.", RuntimeWarning, stacklevel=3)
+            warnings.warn(f"sageattention_amd: a one-launch K/V pre-pass on {self.device} stopped waiting for the other slabs of a head "
+                          "(compute units held by another stream?) and recomputed the head's statistics per workgroup: that call was "
+                          "correct but slow.  This device's calls take the kernel sequence from now on.", RuntimeWarning, stacklevel=3)
         return not self.tripped
 
     def reset(self) -> None:          # tests
@@ -419,8 +420,8 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     if _DEBUG:
         n = prepass_failed_heads(sync, B, H)
         if n:
-            raise _cabi.SageKernelError(f"sage_prepass_kv: {n} (K|V, batch, head) entries gave up waiting for the other slabs of "
-                                        "their head (outputs are NaN-poisoned); is the stream restricted to few compute units?")
+            warnings.warn(f"sage_prepass_kv: in {n} (K|V, batch, head) entries a workgroup stopped waiting for the other slabs of its head and "
+                          "recomputed the statistics itself (slow, not wrong); is the stream restricted to few compute units?", RuntimeWarning)
     return km, k_int8, k_scale, v_image, v_scale, vm
 
 
@@ -472,7 +473,8 @@ def prepass_kv_varlen(k: torch.Tensor, v: Optional[torch.Tensor], cu_seqlens_k: 
     if _DEBUG:
         n = prepass_failed_heads(sync, 1, H)
         if n:
-            raise _cabi.SageKernelError(f"sage_prepass_kv_varlen: {n} heads gave up waiting for their other slabs (outputs are NaN-poisoned)")
+            warnings.warn(f"sage_prepass_kv_varlen: in {n} heads a workgroup stopped waiting for the other slabs and recomputed the statistics "
+                          "itself (slow, not wrong)", RuntimeWarning)
     return km, k_int8, k_scale, v_image
 
 

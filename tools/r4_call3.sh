@@ -1,7 +1,7 @@
 #!/bin/bash
 tag="${TAG:-r4d}"; out="gpurun_out/$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 600 python -m pytest tests/test_gpu_prepass.py tests/test_gpu_parity.py -q -m gpu --timeout 600 -k "prepass or pre_pass or varlen or smooth_v or config3 or prep_v or quant" 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|^E  " | tail -30 | tee "$out/tests.log"
+timeout 600 python -m pytest tests/test_gpu_prepass.py tests/test_gpu_parity.py -q -m gpu --timeout 600 -k "prepass or pre_pass or varlen or smooth_v or config3 or prep_v or quant or give or compute_units or barrier" 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|^E  " | tail -30 | tee "$out/tests.log"
 for shape in 2,32,8192,128 2,48,17776,64 1,16,32768,128; do
     timeout 300 python tools/prepass_ab.py --shape $shape main ppold 2>&1 | grep median
 done | tee "$out/prepass_ab.txt"
