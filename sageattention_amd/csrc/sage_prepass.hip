@@ -214,7 +214,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 __builtin_memcpy(&b, &m1, 4);
                 am01 = __builtin_elementwise_max(am01, a);
                 am23 = __builtin_elementwise_max(am23, b);
-                asm volatile("" ::: "memory");              // keep the rows in order: hoisting the masks costs a register per row
+                asm volatile("" : "+v"(am01), "+v"(am23) :: "memory");      // keep the rows in order (tie the accumulators)
             }
             mx[0] = ld16<DT>(am01[0]); mx[1] = ld16<DT>(am01[1]); mx[2] = ld16<DT>(am23[0]); mx[3] = ld16<DT>(am23[1]);
 #pragma unroll
@@ -534,7 +534,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                     if ((tid & 31) == 0) atomicMax(&gmax[(i * RPI) >> bsh][g_thread], __float_as_uint(m));
                     amax = 0.0f;
                 }
-                asm volatile("" ::: "memory");              // keep the rows in order: hoisting them all spills
+                asm volatile("" : "+v"(amax), "+v"(amax16) :: "memory");      // keep the rows in order (hoisting them all spills): tie the accumulators
             }
             __syncthreads();
             SAGE_STAMP();                          // 5 (K): group maxima
