@@ -115,8 +115,10 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
  *   work_items  (nullable) the work list of the attention launch: (sequence, 128-row query block) int32 pairs for every query block that
  *               exists, sorted by descending weight = 64-key tiles the block visits under `is_causal` (ties: sequence index, then the
  *               later block first); the caller allocates 2 * (ceil(sum Lq / 128) + nseq) ints, a host-known bound of the count
- *   slab_first / slab_seq  (nullable, together) the 512-token slabs of sage_prepass_kv_varlen: prefix sums of ceil(Lk_i / 512)
- *               (nseq + 1) and slab -> sequence (caller allocates ceil(sum Lk / 512) + nseq ints)
+ *   slab_first / slab_seq  (nullable, together) the 512-token slabs of sage_prepass_kv_varlen: prefix sums of the slab counts of the nseq
+ *               sequences and of two gap segments -- rows cu_k[nseq] .. total_k and rows 0 .. cu_k[0] of the packed tensors, which belong to no
+ *               sequence but which `k.mean(dim=0)` (core.py:432-434) still averages over: statistics only -- (nseq + 3 ints), and slab ->
+ *               segment (caller allocates ceil(total_k / 512) + nseq + 2 ints; total_k = rows of the packed k / v)
  *   hdr         (needed by work_items / slab_seq) 8 ints: number of work items, then the launch plan over them as for a dense causal
  *               launch of Hq heads (csrc/sage_work_order.h: heads per group -- whole GQA groups --, fold, left-over heads), the number
  *               of slabs, max Lk, sum Lk, 0
@@ -124,7 +126,7 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
  * Replaces: the torch prefix sums of quant_per_block_varlen.py:68-73 and the `.item()` synchronisations of :75-76; the reference launches
  * ceil(max_seqlen_q / 128) blocks for EVERY sequence and lets the ones past a sequence's end exit (attn_qk_int8_block_varlen.py:98-121). */
 SAGE_API int sage_varlen_plan_max_seqs(void);
-SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
+SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int total_k, int blkq, int blkk,
                               int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
                               int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
                               int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream);
@@ -209,7 +211,7 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  * 512-token slabs of sage_varlen_plan (slab_first / slab_seq / hdr) -- the partition, hence the bits, of sage_prepass_kv_varlen.
  * ws: sage_stats_ws_floats(1, H, 512 * nslab_bound, D) floats. */
 SAGE_API int sage_channel_mean_varlen(const void *x, void *mean_out, float *ws, const int32_t *cu_seqlens, const int32_t *slab_first,
-                                      const int32_t *slab_seq, const int32_t *hdr, int total_tokens, int nslab_bound, int H, int D,
+                                      const int32_t *slab_seq, const int32_t *hdr, int nseq, int total_tokens, int nslab_bound, int H, int D,
                                       int64_t x_sl, int64_t x_sh, int dtype, void *stream);
 SAGE_API int64_t sage_prepass_ws_floats(int B, int H, int L, int D);
 SAGE_API int64_t sage_prepass_sync_words(int B, int H);
@@ -236,7 +238,7 @@ SAGE_API int sage_prepass_kv(const void *k, const void *v, void *k_mean, int8_t 
  *      sage_channel_mean (over the same slabs) + sage_quant_qk_int8_varlen;
  *   V: the fp16 tile image [cu_k_scale[nseq], H, D, 64] of sage_prep_v_f16_varlen (v NULL: K half only).
  * A slab is 512 tokens of ONE sequence (so scale blocks and V tiles never straddle slabs); cu_k_scale, slab_first, slab_seq and hdr come
- * from sage_varlen_plan.  nslab_bound = the host-known bound ceil(total_tokens / 512) + nseq sizes the grid and the workspace
+ * from sage_varlen_plan.  nslab_bound = the host-known bound ceil(total_tokens / 512) + nseq + 2 sizes the grid and the workspace
  * (ws: 2 * H * nslab_bound * 3 * D floats = sage_prepass_ws_floats(1, H, 512 * nslab_bound, D); sync: sage_prepass_sync_words(1, H)).
  * With k_mean the slabs of a head -- all sequences -- wait for each other inside the launch: nslab_bound must not exceed 128 nor the compute
  * units `stream` may use (SAGE_EINVAL otherwise: take the three-call sequence).  A workgroup that gives up recomputes, as in sage_prepass_kv. */

@@ -39,7 +39,7 @@ SYMBOLS = {
                                           _I, _F, _I, _P]),
     "sage_stats_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_channel_mean": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
-    "sage_channel_mean_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
+    "sage_channel_mean_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _P]),
     "sage_prep_v_fp8": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _F, _I, _P]),
     "sage_prepass_ws_floats": (c_int64, [_I, _I, _I, _I]),
     "sage_prepass_sync_words": (c_int64, [_I, _I]),
@@ -69,7 +69,7 @@ SYMBOLS = {
     "sage_attn_fused_q_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
     "sage_varlen_plan_max_seqs": (c_int, []),
-    "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sage_debug_varlen_items": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sage_attn_fused_qblock_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),

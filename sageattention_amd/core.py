@@ -409,7 +409,9 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
     synchronisation on the default route: the index arrays (``sage_varlen_plan``), the K / V pre-pass (``sage_prepass_kv_varlen``) and
     the attention kernel over a device-built work list (every workgroup one existing query block, heaviest first) with the per-block Q
     quantisation in its prologue.  Route switches (same bits either way): ``fused_prepass=False`` the kernel sequence,
-    ``work_list=False`` the unit order sized by ``max_seqlen_q``, ``fuse_q_quant=False`` a separate Q quantiser."""
+    ``work_list=False`` the unit order sized by ``max_seqlen_q``, ``fuse_q_quant=False`` a separate Q quantiser; ``varlen_plan=False`` builds
+    the index arrays with torch ops as for more than 1024 sequences (the K mean is then summed over packed 512-token slabs instead of
+    per-sequence ones: equal up to the last bit of an input-dtype rounding)."""
     return _varlen_attend(_varlen_prepare(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal, sm_scale, smooth_k,
                                           kwargs))
 

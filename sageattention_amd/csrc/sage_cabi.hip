@@ -202,7 +202,7 @@ SAGE_API int sage_quant_qk_int8_varlen(const void *x, const void *mean, int8_t *
 }
 
 SAGE_API int sage_varlen_plan_max_seqs(void) { return sage::kVarlenPlanMaxSeq; }
-SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int blkq, int blkk,
+SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int total_k, int blkq, int blkk,
                               int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
                               int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
                               int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream)
@@ -216,7 +216,8 @@ SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seq
                  "the launch plan needs Hq %% Hkv == 0 and head_dim 64 / 128 (got %d, %d, %d)", Hq, Hkv, head_dim);
     SAGE_REQUIRE((slab_seq == nullptr) == (slab_first == nullptr) && (slab_seq == nullptr || hdr != nullptr), "slab_seq, slab_first and hdr come together");
     sage::VarlenPlanParams p{};
-    p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k; p.nseq = nseq; p.blkq = blkq; p.blkk = blkk;
+    SAGE_REQUIRE(slab_seq == nullptr || total_k > 0, "the slab map needs total_k, the row count of the packed k / v tensors");
+    p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k; p.nseq = nseq; p.blkq = blkq; p.blkk = blkk; p.total_k = total_k;
     p.causal = is_causal ? 1 : 0; p.Hq = Hq > 0 ? Hq : 1; p.Hkv = Hkv > 0 ? Hkv : 1; p.head_dim = head_dim; p.pv_fp8 = pv_fp8 ? 1 : 0;
     p.cu_qs = cu_q_scale; p.cu_ks = cu_k_scale; p.order = seq_order; p.items = work_items;
     p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
@@ -298,10 +299,10 @@ SAGE_API int sage_channel_mean(const void *x, void *mean_out, float *ws, int B, 
 }
 
 SAGE_API int sage_channel_mean_varlen(const void *x, void *mean_out, float *ws, const int32_t *cu_seqlens, const int32_t *slab_first,
-                                      const int32_t *slab_seq, const int32_t *hdr, int total_tokens, int nslab_bound, int H, int D,
+                                      const int32_t *slab_seq, const int32_t *hdr, int nseq, int total_tokens, int nslab_bound, int H, int D,
                                       int64_t x_sl, int64_t x_sh, int dtype, void *stream)
 {
-    SAGE_REQUIRE(x && ws && mean_out && cu_seqlens && slab_first && slab_seq && hdr, "null tensor pointer");
+    SAGE_REQUIRE(x && ws && mean_out && cu_seqlens && slab_first && slab_seq && hdr && nseq > 0, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d)", D);
     SAGE_REQUIRE(H > 0 && total_tokens > 0 && nslab_bound >= (total_tokens + sage::kStatsSlab - 1) / sage::kStatsSlab, "empty tensor or nslab_bound too small");
     SAGE_REQUIRE(dtype == SAGE_DTYPE_F16 || dtype == SAGE_DTYPE_BF16, "bad dtype %d", dtype);
@@ -310,7 +311,7 @@ SAGE_API int sage_channel_mean_varlen(const void *x, void *mean_out, float *ws, 
     p.x = x; p.ws = ws; p.stats = nullptr; p.mean_out = mean_out;
     p.B = 1; p.H = H; p.L = total_tokens; p.D = D; p.nslab = nslab_bound;
     p.x_sb = 0; p.x_sh = x_sh; p.x_sl = x_sl; p.dtype = dtype;
-    p.cu = cu_seqlens; p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
+    p.cu = cu_seqlens; p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr; p.nseq = nseq;
     return check_launch(sage::launch_stats(p, static_cast<hipStream_t>(stream)), "sage_channel_mean_varlen launch");
 }
 
@@ -523,7 +524,7 @@ SAGE_API int sage_prepass_kv_varlen(const void *k, const void *v, void *k_mean, 
     p.dtype = dtype; p.scale_max = 448.0f; p.v_fp16 = 1;
     p.debug_fail = g_prepass_debug_fail;
     p.host_flag = host_flag;
-    p.cu = cu_seqlens_k; p.cu_tiles = cu_k_scale; p.slab_seq = slab_seq; p.slab_first = slab_first; p.hdr = hdr;
+    p.cu = cu_seqlens_k; p.cu_tiles = cu_k_scale; p.slab_seq = slab_seq; p.slab_first = slab_first; p.hdr = hdr; p.nseq = nseq;
     return check_launch(sage::launch_prepass_kv(p, static_cast<hipStream_t>(stream)), "sage_prepass_kv_varlen launch");
 }
 

@@ -91,4 +91,15 @@ __device__ inline float pair_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// packed (varlen) batches: rows [t0, t0 + len) of segment `seg` of a tensor of `total` rows -- a sequence (seg < nseq), or one of the two
+// gaps outside every sequence that `k.mean(dim=0)` still averages over (core.py:432-434): nseq = the tail, nseq + 1 = the head
+template <typename IntPtr>          // (a generic pointer, or a constant-address-space one for scalar loads)
+__device__ __forceinline__ void varlen_segment(IntPtr cu, int nseq, int total, int seg, int &t0, int &len)
+{
+    if (seg < nseq) { t0 = cu[seg]; len = cu[seg + 1] - t0; }
+    else if (seg == nseq) { t0 = cu[nseq]; len = total - t0; }
+    else { t0 = 0; len = cu[0]; }
+    len = len > 0 ? len : 0;
+}
+
 }  // namespace sage

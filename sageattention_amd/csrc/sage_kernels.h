@@ -89,13 +89,15 @@ constexpr int kVarlenHdrWords = 8;       // hdr: nitems, group, fold, left, nsla
 struct VarlenPlanParams {
     const int32_t *cu_q, *cu_k;          // [nseq + 1]
     int nseq, blkq, blkk;
+    int total_k;                         // rows of the packed k / v tensors (>= cu_k[nseq]): rows outside every sequence still count in the K mean
     int causal, Hq, Hkv, head_dim, pv_fp8;   // for the launch plan (hdr) only
     int32_t *cu_qs;                      // nullable [nseq + 1]
     int32_t *cu_ks;                      // [nseq + 1]
     int32_t *order;                      // nullable [nseq]
     int32_t *items;                      // nullable [2 * nitems]: (sequence, query block), heaviest first
-    int32_t *slab_first;                 // nullable [nseq + 1]: prefix sums of ceil(Lk_i / 512)
-    int32_t *slab_seq;                   // nullable [nslab]: slab -> sequence
+    int32_t *slab_first;                 // nullable [nseq + 3]: prefix sums of the slab counts of the nseq sequences, then of two "gap" segments
+                                         // (index nseq: rows cu_k[nseq] .. total_k, index nseq + 1: rows 0 .. cu_k[0]) that only the K mean reads
+    int32_t *slab_seq;                   // nullable [nslab]: slab -> segment (sequence, or nseq / nseq + 1 for the gaps)
     int32_t *hdr;                        // nullable [kVarlenHdrWords]
 };
 hipError_t launch_varlen_plan(const VarlenPlanParams &p, hipStream_t stream);
@@ -113,8 +115,9 @@ struct StatsParams {
     int B, H, L, D, nslab;
     long x_sb, x_sh, x_sl;
     int dtype;
-    // packed batches (nullable, together): slabs per sequence as sage_varlen_plan lays them out; nslab = host-known bound, L = sum L
+    // packed batches (nullable, together): slabs per segment as sage_varlen_plan lays them out; nslab = host-known bound, L = rows of x
     const int32_t *cu, *slab_first, *slab_seq, *hdr;
+    int nseq;
 };
 hipError_t launch_stats(const StatsParams &p, hipStream_t stream);
 
@@ -171,9 +174,10 @@ struct PrepassParams {
     // sequences (core.py:432-434).  B = 1, L = sum L (the mean's divisor), nslab = host-known bound of the slab count (grid, workspace)
     const int32_t *cu;        // null => dense.  cu_seqlens_k [nseq + 1]
     const int32_t *cu_tiles;  // prefix sums of ceil(L_i / 64): k scale block / V tile index of a sequence's first block
-    const int32_t *slab_seq;  // slab -> sequence
-    const int32_t *slab_first;// prefix sums of ceil(L_i / 512)
+    const int32_t *slab_seq;  // slab -> segment: a sequence, or a gap (nseq: rows cu[nseq] .. L, nseq + 1: rows 0 .. cu[0]; statistics only)
+    const int32_t *slab_first;// prefix sums of the segments' slab counts
     const int32_t *hdr;       // sage_varlen_plan's header: hdr[4] = number of slabs that exist
+    int nseq;                 // number of sequences (segments >= nseq are gaps)
 };
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t stream);
 hipError_t launch_debug_spin(int ms, int nwg, hipStream_t stream);

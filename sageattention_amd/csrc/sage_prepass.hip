@@ -135,15 +135,20 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
     const int gslab = blockIdx.x, h = blockIdx.y;          // gslab: index among the head's slabs (the statistics / barrier index)
     int slab = gslab, L = p.L, nslab = p.nslab;            // slab: index inside the sequence; L: rows of the sequence; nslab: slabs of the head
     long tok0 = 0, tile0 = 0;                              // VARLEN: first packed token / first 64-key block of the sequence
+    bool gap = false;
     if constexpr (VARLEN) {
         typedef const __attribute__((address_space(4))) int *cint_p;          // wave-uniform: scalar loads
         nslab = ((cint_p)p.hdr)[4];
         if (gslab >= nslab) return;                        // the grid is sized by a host-known bound (workgroup-uniform exit)
-        const int seq = ((cint_p)p.slab_seq)[gslab];
-        slab = gslab - ((cint_p)p.slab_first)[seq];
-        tok0 = ((cint_p)p.cu)[seq];
-        L = ((cint_p)p.cu)[seq + 1] - (int)tok0;
-        tile0 = ((cint_p)p.cu_tiles)[seq];
+        const int seg = ((cint_p)p.slab_seq)[gslab];
+        slab = gslab - ((cint_p)p.slab_first)[seg];
+        int t0, len;
+        varlen_segment((cint_p)p.cu, p.nseq, p.L, seg, t0, len);
+        tok0 = t0;
+        L = len;
+        gap = seg >= p.nseq;                                // rows outside every sequence: they count in the K mean and nowhere else
+        if (gap && (IS_V || p.k_mean == nullptr)) return;
+        tile0 = gap ? 0 : ((cint_p)p.cu_tiles)[seg];
     }
     const long bh = (long)b * p.H + h;
     const long x_sl = is_v ? p.v_sl : p.k_sl;
@@ -300,11 +305,11 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 int Li = L, si = i;
                 if constexpr (VARLEN) {
                     typedef const __attribute__((address_space(4))) int *cint_p;
-                    const int seq = ((cint_p)p.slab_seq)[i];
-                    si = i - ((cint_p)p.slab_first)[seq];
-                    const long t0 = ((cint_p)p.cu)[seq];
-                    Li = ((cint_p)p.cu)[seq + 1] - (int)t0;
-                    xi = x + (t0 - tok0) * x_sl;
+                    const int seg = ((cint_p)p.slab_seq)[i];
+                    si = i - ((cint_p)p.slab_first)[seg];
+                    int t0;
+                    varlen_segment((cint_p)p.cu, p.nseq, p.L, seg, t0, Li);
+                    xi = x + ((long)t0 - tok0) * x_sl;
                 }
                 const int rbeg = si * kStatsSlab + r0, rend = min(Li, si * kStatsSlab + kStatsSlab);
                 float fx[4], fn[4], fs[4];
@@ -403,6 +408,7 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
             }
         }
     }
+    if (gap) return;                                        // (workgroup-uniform; the slab has arrived, departed and is needed no further)
     if (SAGE_PP_ABL & 2) {
         unsigned acc = 0;
 #pragma unroll

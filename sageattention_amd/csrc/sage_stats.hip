@@ -32,9 +32,11 @@ stats_partial_kernel(const StatsParams p)
     int start = slab * kStatsSlab, end = min(p.L, slab * kStatsSlab + kStatsSlab);
     if (p.slab_seq != nullptr) {
         if (slab >= p.hdr[4]) return;
-        const int seq = p.slab_seq[slab];
-        start = p.cu[seq] + (slab - p.slab_first[seq]) * kStatsSlab;
-        end = min(p.cu[seq + 1], start + kStatsSlab);
+        const int seg = p.slab_seq[slab];
+        int t0, len;
+        varlen_segment(p.cu, p.nseq, p.L, seg, t0, len);
+        start = t0 + (slab - p.slab_first[seg]) * kStatsSlab;
+        end = min(t0 + len, start + kStatsSlab);
     }
     // eight independent 16-byte loads in flight per thread: with one load per thread the 1024-workgroup grid keeps
     // only ~4 MB in flight chip-wide, half of what a cold HBM read stream needs; rows are still accumulated in order

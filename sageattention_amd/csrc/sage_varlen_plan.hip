@@ -5,7 +5,8 @@
 //   order           the sequences by descending query length                       (legacy unit order of the attention launcher)
 //   items / hdr     the work list of the attention launch: every existing (sequence, 128-row query block) pair, sorted by descending
 //                   weight (csrc/sage_work_order.h), and the launch plan over it {nitems, group, fold, left, nslab, max Lk, sum Lk}
-//   slab_first / slab_seq   the 512-token slabs of the K / V pre-pass, per sequence (prefix sums and slab -> sequence map)
+//   slab_first / slab_seq   the 512-token slabs of the K / V pre-pass, per sequence (prefix sums and slab -> sequence map), plus the slabs of
+//                   the rows outside every sequence (two gap segments), which only the K mean reads
 // One workgroup: nseq <= kVarlenPlanMaxSeq; Hillis-Steele scans in LDS, ranks by the closed-form counts of sage_work_order.h.
 #include "sage_common.h"
 #include "sage_kernels.h"
@@ -55,16 +56,20 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
             p.order[rank] = i;
         }
     }
-    const int nitems = sq[cur][nseq - 1], nslab = ss[cur][nseq - 1];
+    // two more slab-owning segments, read by the K mean only: the rows behind the last sequence and in front of the first one
+    const int nslab_seq = ss[cur][nseq - 1];
+    const int tail = max(p.total_k - p.cu_k[nseq], 0), head = max(p.cu_k[0], 0);
+    const int nslab_tail = (tail + kStatsSlab - 1) / kStatsSlab, nslab_head = (head + kStatsSlab - 1) / kStatsSlab;
+    const int nitems = sq[cur][nseq - 1], nslab = nslab_seq + nslab_tail + nslab_head;
     if (i == 0) {
         if (p.cu_qs != nullptr) p.cu_qs[0] = 0;
         p.cu_ks[0] = 0;
-        if (p.slab_first != nullptr) p.slab_first[0] = 0;
+        if (p.slab_first != nullptr) { p.slab_first[0] = 0; p.slab_first[nseq + 1] = nslab_seq + nslab_tail; p.slab_first[nseq + 2] = nslab; }
         if (p.hdr != nullptr) {
             WorkOrder w;
             plan_varlen_order(w, p.Hq, p.Hq / p.Hkv, nitems, (long)max_lk, p.head_dim, p.pv_fp8 != 0);
             p.hdr[0] = nitems; p.hdr[1] = w.group; p.hdr[2] = w.fold; p.hdr[3] = w.left;
-            p.hdr[4] = nslab; p.hdr[5] = max_lk; p.hdr[6] = p.cu_k[nseq] - p.cu_k[0]; p.hdr[7] = 0;
+            p.hdr[4] = nslab; p.hdr[5] = max_lk; p.hdr[6] = p.cu_k[nseq] - p.cu_k[0]; p.hdr[7] = nslab - nslab_seq;
         }
     }
     // inclusive scan value of sequence t = number of blocks / slabs in sequences 0 .. t: the first t with scan[t] > idx owns index idx
@@ -86,7 +91,8 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
         }
     }
     if (p.slab_seq != nullptr) {
-        for (int idx = i; idx < nslab; idx += 1024) p.slab_seq[idx] = owner(ss[cur], idx);
+        for (int idx = i; idx < nslab; idx += 1024)
+            p.slab_seq[idx] = idx < nslab_seq ? owner(ss[cur], idx) : (idx < nslab_seq + nslab_tail ? nseq : nseq + 1);
     }
 }
 

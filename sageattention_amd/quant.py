@@ -149,10 +149,10 @@ class VarlenPlan(NamedTuple):
     order: torch.Tensor                # [nseq] sequences by descending query length (launches without a work list)
     items: Optional[torch.Tensor]      # [items_bound, 2] (sequence, query block), heaviest first -- the attention launch's work list
     hdr: Optional[torch.Tensor]        # [8] number of items, launch plan (group, fold, left), number of slabs, max Lk, sum Lk
-    slab_first: Optional[torch.Tensor]  # [nseq + 1] prefix sums of ceil(Lk_i / 512)
-    slab_seq: Optional[torch.Tensor]   # [slab_bound] slab -> sequence (K / V pre-pass)
+    slab_first: Optional[torch.Tensor]  # [nseq + 3] prefix sums of the slab counts: the sequences, then the rows behind the last / before the first one
+    slab_seq: Optional[torch.Tensor]   # [slab_bound] slab -> segment (K / V pre-pass; nseq / nseq + 1 = the gap rows, which only the K mean reads)
     items_bound: int                   # host-known bound of the item count: ceil(sum Lq / 128) + nseq
-    slab_bound: int                    # host-known bound of the slab count: ceil(sum Lk / 512) + nseq
+    slab_bound: int                    # host-known bound of the slab count: ceil(rows of k / 512) + nseq + 2
 
 
 @_eager
@@ -176,12 +176,12 @@ def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: in
     work = total_q is not None and total_k is not None and BLKQ == 128 and BLKK == 64
     if work:
         items_bound = (int(total_q) + 127) // 128 + nseq
-        slab_bound = (int(total_k) + 511) // 512 + nseq
+        slab_bound = (int(total_k) + 511) // 512 + nseq + 2          # (+ 2: the gap segments outside every sequence, see the header)
         items = torch.empty((items_bound, 2), dtype=torch.int32, device=dev)
         hdr = torch.empty((8,), dtype=torch.int32, device=dev)
-        slab_first = torch.empty((nseq + 1,), dtype=torch.int32, device=dev)
+        slab_first = torch.empty((nseq + 3,), dtype=torch.int32, device=dev)
         slab_seq = torch.empty((slab_bound,), dtype=torch.int32, device=dev)
-    rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, BLKQ, BLKK, int(is_causal), int(Hq), int(Hkv), int(head_dim),
+    rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, int(total_k) if work else 0, BLKQ, BLKK, int(is_causal), int(Hq), int(Hkv), int(head_dim),
                               int(pv_fp8), _p(cu_qs), _p(cu_ks), _p(order), _p(items), _p(slab_first), _p(slab_seq), _p(hdr),
                               _stream(cu_seqlens_q))
     _cabi.check(rc, "sage_varlen_plan")
@@ -269,7 +269,7 @@ def channel_mean_packed(x: torch.Tensor, cu_seqlens: Optional[torch.Tensor] = No
     if plan is not None and plan.slab_seq is not None:
         ws = _stats_ws(1, H, 512 * plan.slab_bound, D, x.device)
         rc = _cabi.load().sage_channel_mean_varlen(_p(x), _p(out), _p(ws), _p(cu_seqlens), _p(plan.slab_first), _p(plan.slab_seq), _p(plan.hdr),
-                                                   T, plan.slab_bound, H, D, x.stride(0), x.stride(1), _dtype_code(x), _stream(x))
+                                                   cu_seqlens.shape[0] - 1, T, plan.slab_bound, H, D, x.stride(0), x.stride(1), _dtype_code(x), _stream(x))
         _cabi.check(rc, "sage_channel_mean_varlen")
         return out
     ws = _stats_ws(1, H, T, D, x.device)

@@ -1105,7 +1105,9 @@ def test_varlen_plan_matches_the_torch_prefix_sums():
             o = plan.order.cpu().long()
             assert sorted(o.tolist()) == list(range(nseq)) and (lq[o][:-1] >= lq[o][1:]).all()
             nslab = (lk + 511) // 512
-            assert torch.equal(plan.slab_first.cpu(), torch.nn.functional.pad(nslab.cumsum(0), (1, 0)).to(torch.int32))
+            sf = plan.slab_first.cpu()
+            assert torch.equal(sf[:nseq + 1], torch.nn.functional.pad(nslab.cumsum(0), (1, 0)).to(torch.int32))
+            assert sf[nseq + 1] == sf[nseq] == sf[nseq + 2]                       # no rows outside the sequences here: the gap segments are empty
             assert torch.equal(plan.slab_seq.cpu()[:int(nslab.sum())], torch.repeat_interleave(torch.arange(nseq), nslab).to(torch.int32))
             hdr = plan.hdr.cpu().numpy()
             nitems = int(((lq + 127) // 128).sum())
@@ -1181,6 +1183,43 @@ def test_varlen_routes_are_bit_identical(causal, dt, D, hq, hkv):
         torch.cuda.synchronize()
         assert torch.isfinite(o.float()).all()
         assert torch.equal(o, o_seq) and torch.equal(o, o_unit) and torch.equal(o, o_both)
+
+
+def test_varlen_rows_outside_every_sequence_still_count_in_the_k_mean():
+    """`km = k.mean(dim=0)` (core.py:432-434) averages over EVERY row of the packed k, also rows that belong to no sequence (a packed tensor
+    padded behind cu_seqlens[-1], or cu_seqlens[0] > 0).  The per-sequence slabs of the plan are joined by two gap segments that only the
+    statistics read: the mean is the mean over all rows on both routes, bit-equal between them, and the attention result equals the
+    result of the same call on the tight tensors with that mean."""
+    g = torch.Generator().manual_seed(31)
+    head, lens, tail = 700, [300, 1100, 64, 513], 900
+    total = head + sum(lens) + tail
+    hq, hkv, D = 4, 2, 128
+    q = torch.randn(total, hq, D, generator=g).to(torch.bfloat16).to(DEV)
+    k = (torch.randn(total, hkv, D, generator=g) * 1.3 + torch.randn(1, hkv, D, generator=g)).to(torch.bfloat16).to(DEV)
+    k[:head] += 3.0                                                  # the gap rows move the mean visibly
+    k[-tail:] -= 2.0
+    v = torch.randn(total, hkv, D, generator=g).to(torch.bfloat16).to(DEV)
+    cu = torch.tensor([head + x for x in [0] + list(np.cumsum(lens))], dtype=torch.int32, device=DEV)
+    plan = sq.varlen_plan(cu, cu, total_q=total, total_k=total, Hq=hq, Hkv=hkv, head_dim=D)
+    hdr = plan.hdr.cpu().numpy()
+    nslab_seq = sum((x + 511) // 512 for x in lens)
+    assert hdr[4] == nslab_seq + (tail + 511) // 512 + (head + 511) // 512 and hdr[7] == hdr[4] - nslab_seq
+    km1, k81, ks1, img1 = sq.prepass_kv_varlen(k, v, cu, plan, max(lens))
+    km0 = sq.channel_mean_packed(k, cu, plan)
+    want = k.float().mean(dim=0, keepdim=True)
+    torch.cuda.synchronize()
+    assert torch.equal(km1.view(torch.int16), km0.view(torch.int16))
+    assert (km1.float() - want).abs().max().item() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+    assert (km1.float() - k[head:head + sum(lens)].float().mean(dim=0, keepdim=True)).abs().max().item() > 0.05     # (not the mean of the sequences alone)
+    _, _, k80, ks0, _, _ = sq.per_block_int8_varlen(None, k, cu, cu, max(lens), max(lens), km=km0, cu_ks=plan.cu_ks)
+    nblk = int(plan.cu_ks[-1].item())
+    lo, hi = head, head + sum(lens)
+    assert torch.equal(k81[lo:hi], k80[lo:hi]) and torch.equal(ks1[:nblk].view(torch.int32), ks0[:nblk].view(torch.int32))
+    for causal in (False, True):
+        o = sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal)
+        o_seq = sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal, fused_prepass=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o[lo:hi].float()).all() and torch.equal(o[lo:hi], o_seq[lo:hi])
 
 
 def test_varlen_with_more_sequences_than_the_plan_takes(oracle_mod):
