@@ -28,3 +28,14 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _fresh_prepass_guard(request):
+    """GPU tests start with the one-launch pre-pass allowed on every device: a test that makes a pre-pass give up (on purpose, or because it
+    crowds the chip) trips the per-device guard, which would silently move every later test of the process onto the kernel sequence."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from sageattention_amd import quant
+        for g in quant._PrepassGuard._by_device.values():
+            g.reset()
+    yield
