@@ -1222,6 +1222,42 @@ def test_varlen_rows_outside_every_sequence_still_count_in_the_k_mean():
         assert torch.isfinite(o[lo:hi].float()).all() and torch.equal(o[lo:hi], o_seq[lo:hi])
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_with_empty_sequences(causal):
+    """Sequences of length zero (repeated entries of cu_seqlens; the reference's grid lets their blocks exit, attn_qk_int8_block_varlen.py:98-121):
+    no work item, no slab, no scale block.  The call must equal, bit for bit, the call on the same packed tensors with the empty sequences
+    removed from cu_seqlens -- on the planned route, on the kernel sequence and on the unit order."""
+    g = torch.Generator().manual_seed(5)
+    lens_full = [0, 200, 0, 0, 1025, 64, 0, 513, 0]
+    lens = [x for x in lens_full if x > 0]
+    hq, hkv, D = 8, 2, 128
+    total = sum(lens)
+    q = torch.randn(total, hq, D, generator=g).to(torch.bfloat16).to(DEV)
+    k = (torch.randn(total, hkv, D, generator=g) + torch.randn(1, hkv, D, generator=g)).to(torch.bfloat16).to(DEV)
+    v = torch.randn(total, hkv, D, generator=g).to(torch.bfloat16).to(DEV)
+    cu_full = torch.tensor([0] + list(np.cumsum(lens_full)), dtype=torch.int32, device=DEV)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    want = sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal)
+    for kw in ({}, {"fused_prepass": False}, {"work_list": False}, {"fused_prepass": False, "work_list": False, "fuse_q_quant": False}):
+        o = sa.sageattn_varlen(q, k, v, cu_full, cu_full, max(lens), max(lens), is_causal=causal, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all() and torch.equal(o, want), kw
+    # keys but no queries / queries but no keys in one sequence (cu_seqlens_q != cu_seqlens_k): rows without keys are zero, as the
+    # reference's accumulators are (acc = 0, l_i = 1: attn_qk_int8_block_varlen.py:57-58)
+    if not causal:
+        lq, lk = [128, 0, 300, 70], [200, 64, 0, 70]
+        q2 = torch.randn(sum(lq), hq, D, generator=g).to(torch.bfloat16).to(DEV)
+        k2 = torch.randn(sum(lk), hkv, D, generator=g).to(torch.bfloat16).to(DEV)
+        v2 = torch.randn(sum(lk), hkv, D, generator=g).to(torch.bfloat16).to(DEV)
+        cq = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32, device=DEV)
+        ck = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32, device=DEV)
+        o = sa.sageattn_varlen(q2, k2, v2, cq, ck, max(lq), max(lk))
+        o_seq = sa.sageattn_varlen(q2, k2, v2, cq, ck, max(lq), max(lk), fused_prepass=False, work_list=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all() and torch.equal(o, o_seq)
+        assert (o[128:428] == 0).all() and (o[:128] != 0).any()
+
+
 def test_varlen_with_more_sequences_than_the_plan_takes(oracle_mod):
     """More than sage_varlen_plan_max_seqs() sequences: no plan, so torch prefix sums, an on-device argsort for the unit order, the kernel
     sequence, the Q quantiser fused in the attention prologue -- exercised end to end (round 3 only checked that the planner returns None).
