@@ -71,6 +71,9 @@
 #ifndef SAGE_RSUM_MFMA   // experiment: FP16-PV CUDA form, pipelined loop: the row sum of the fp16-rounded P from the matrix pipe (a ones
 #define SAGE_RSUM_MFMA 0 // fragment against P, the reference's mma::rowsum_f16f16f32) instead of two v_fma_mix_f32 per score pair
 #endif
+#ifndef SAGE_ATTN_TRACE      // experiment (tools/attn_trace.py): wave 0 of every workgroup records 100 MHz time stamps of its phases
+#define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
+#endif
 #ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
 #define SAGE_ORDER_DEFAULT -1
 #endif
@@ -149,6 +152,15 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 #endif
 }
 
+#if SAGE_ATTN_TRACE
+constexpr int kAttnTraceWgs = 1 << 15;
+__device__ unsigned g_attn_trace[16 * kAttnTraceWgs];      // 16 words per workgroup: 8 stamps, -, HW_ID, XCC_ID
+#define SAGE_TSTAMP(i) do { if (wave == 0) { unsigned long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ttrace[i] = (unsigned)t_; } } while (0)
+#else
+#define SAGE_TSTAMP(i) do { } while (0)
+#endif
+
 // QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue, per-thread groups;
 // 3 / 4 = fp16 / bf16 quantised in the prologue PER BLOCK of 128 rows after the multiplication by p.q_premul (quant_per_block.py:21-46
 // with sm_scale folded in: the Q half of the reference's Triton-named API and of sageattn_varlen),
@@ -167,6 +179,10 @@ sage_attn_kernel(const AttnParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31;      // query row inside the wave's 32-row tile
     const int g = lane >> 5;      // k-group (operand half)
+#if SAGE_ATTN_TRACE
+    __shared__ unsigned ttrace[16];
+#endif
+    SAGE_TSTAMP(0);
 
     // ---- work item: XCD-aware, heavy-first --------------------------------------------------
     const int nqblk = p.nqblk;
@@ -224,18 +240,23 @@ sage_attn_kernel(const AttnParams p)
     const float *qs_ptr, *ks_ptr;
     int qs_stride, ks_tstride;
     if (p.cu_q != nullptr) {              // varlen: packed [sum L, H, D]
-        const int q0 = p.cu_q[b], k0 = p.cu_k[b];
-        Lq = p.cu_q[b + 1] - q0;
-        Lk = p.cu_k[b + 1] - k0;
+        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, requested together (as vector loads they
+        // were a memory round trip of their own behind the work list's; measured neutral at C4, profiles/r4_run_p_attention_phase_trace.txt)
+        typedef const __attribute__((address_space(4))) int *cint_p;
+        const int bu = __builtin_amdgcn_readfirstlane(b);
+        const int q0 = ((cint_p)p.cu_q)[bu], k0 = ((cint_p)p.cu_k)[bu], q1 = ((cint_p)p.cu_q)[bu + 1], k1 = ((cint_p)p.cu_k)[bu + 1];
+        const int ks0 = ((cint_p)p.cu_ks)[bu];
+        Lq = q1 - q0;
+        Lk = k1 - k0;
         if (qblk * BLKQ >= Lq) return;
         q_off = (long)q0 * p.q_sl + (long)h * p.q_sh;
         k_off = (long)k0 * p.k_sl + (long)hk * p.k_sh;
         o_off = (long)q0 * p.o_sl + (long)h * p.o_sh;
-        v_tile0 = (long)p.cu_ks[b] * p.Hkv + hk;
+        v_tile0 = (long)ks0 * p.Hkv + hk;
         v_tstride = p.Hkv;
-        qs_ptr = QF == 0 ? p.q_scale + ((long)p.cu_qs[b] + qblk) * p.Hq + h : nullptr;    // [sum nblk, Hq] (fused Q: no stored scales)
+        qs_ptr = QF == 0 ? p.q_scale + ((long)((cint_p)p.cu_qs)[bu] + qblk) * p.Hq + h : nullptr;    // [sum nblk, Hq] (fused Q: no stored scales)
         qs_stride = 0;
-        ks_ptr = p.k_scale + (long)p.cu_ks[b] * p.Hkv + hk;           // [sum nblk, Hkv]
+        ks_ptr = p.k_scale + (long)ks0 * p.Hkv + hk;                  // [sum nblk, Hkv]
         ks_tstride = p.Hkv;
     } else {
         // split-KV (p.kv_split = S > 1): the key range is folded into the kv-head dimension, kv head hk = hk0 * S + chunk and query
@@ -253,6 +274,7 @@ sage_attn_kernel(const AttnParams p)
         ks_tstride = KTHREAD ? 4 : 1;
     }
 
+    SAGE_TSTAMP(1);
     const int row0 = qblk * BLKQ + wave * 32;        // first query row of this wave
     const int my_row = row0 + n;
     // causal mask in the chunk's key coordinates (split-KV: this workgroup sees keys kchunk0 .. kchunk0 + Lk - 1 as 0 .. Lk - 1):
@@ -498,7 +520,9 @@ sage_attn_kernel(const AttnParams p)
         }
     }
 
+    SAGE_TSTAMP(2);
     ring_wait(NSTAGE == 3 && n_iters > 1);
+    SAGE_TSTAMP(3);
 
     int cur = 0;
     // One K/V tile.  STEADY = the tile is whole and unmasked for every wave of the workgroup and tiles it+1, it+2
@@ -1419,7 +1443,9 @@ sage_attn_kernel(const AttnParams p)
 #endif
 #pragma nounroll
     for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
+    SAGE_TSTAMP(4);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
+    SAGE_TSTAMP(5);
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
     const float l_tot = pair_sum(l_run);
@@ -1493,6 +1519,17 @@ sage_attn_kernel(const AttnParams p)
             if (grow < Lq) *reinterpret_cast<v4u *>(obase + 2 * ((long)grow * p.o_sl) + Q * 16) = val;
         }
     }
+#if SAGE_ATTN_TRACE
+    SAGE_TSTAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SAGE_TSTAMP(7);
+    if (wave == 0 && (int)blockIdx.x < kAttnTraceWgs) {
+        if (lane < 8) g_attn_trace[16 * blockIdx.x + lane] = ttrace[lane];
+        if (lane == 9) g_attn_trace[16 * blockIdx.x + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        if (lane == 10) g_attn_trace[16 * blockIdx.x + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        if (lane == 11) g_attn_trace[16 * blockIdx.x + 11] = blockIdx.x;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1648,3 +1685,17 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
 }
 
 }  // namespace sage
+
+#if SAGE_ATTN_TRACE
+extern "C" __attribute__((visibility("default"))) int sage_debug_attn_trace(unsigned *dst_host, int words, int clear)
+{
+    const size_t bytes = (size_t)(words < 16 * sage::kAttnTraceWgs ? words : 16 * sage::kAttnTraceWgs) * sizeof(unsigned);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (dst_host != nullptr && hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(sage::g_attn_trace), bytes) != hipSuccess) return -2;
+    if (clear) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(sage::g_attn_trace)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned) * 16 * sage::kAttnTraceWgs) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
