@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 17
+#define SAGE_ABI_VERSION 18
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -262,6 +262,23 @@ SAGE_API int sage_prep_v_f16(const void *v, void *v_image, const float *v_mean, 
 SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t *cu_seqlens,
                            const int32_t *cu_tiles, int nseq, int max_seqlen, int H, int D,
                            int64_t v_sl, int64_t v_sh, int dtype, void *stream);
+
+/*
+ * Launch workspace of the attention entry points below (optional, a gfx950 launch attribute; the reference has no counterpart: its
+ * kernels leave the order of their thread blocks to the hardware, qk_int_sv_f8_cuda_sm89.cuh:720-738).
+ * sage_attn_launch_ws(ws, bytes) hands the NEXT attention launch issued by THIS host thread a block of device memory of
+ * sage_attn_launch_ws_bytes() bytes, 128-byte aligned, ZEROED by the caller in stream order in front of that launch.  It is a one-shot
+ * attribute, held in a thread-local word: the next sage_attn_* call of the thread consumes it whether it uses it or not (argument
+ * errors included); NULL clears it.  With it a NON-CAUSAL, unmasked launch of at least twelve rounds of workgroups runs as a persistent
+ * launch -- as many workgroups as the device holds at once take the work items as tickets from 32 queues (4 per XCD, own XCD first: the
+ * L2 locality of the work order; then the fullest other queue: the XCDs of a device run a few per cent apart) -- which measured 2.2-2.4 %
+ * faster on the CogVideoX shape and on packed batches (profiles/r4_run_p_attention_phase_trace.txt); every other launch ignores it.
+ * Results do not depend on it.  The block must stay untouched until the launch has finished and may be reused (zeroed again) afterwards.
+ */
+SAGE_API int64_t sage_attn_launch_ws_bytes(void);
+SAGE_API int sage_attn_launch_ws(void *ws, int64_t bytes);
+/* The number of workgroups of this host thread's last attention launch (a persistent launch has fewer than work items): for tests. */
+SAGE_API int sage_debug_last_attn_grid(void);
 
 /*
  * Fused attention, INT8 QK^T + FP8 PV.

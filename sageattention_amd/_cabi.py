@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 17
+ABI_VERSION = 18
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -56,6 +56,9 @@ SYMBOLS = {
     "sage_debug_spin": (c_int, [_I, _I, _P]),
     "sage_prep_v_f16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
     "sage_prep_v_f16_varlen": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
+    "sage_attn_launch_ws_bytes": (c_int64, []),
+    "sage_attn_launch_ws": (c_int, [_P, _L]),
+    "sage_debug_last_attn_grid": (c_int, []),
     "sage_attn_qk_int8_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
     "sage_attn_qk_int8_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,

@@ -110,6 +110,7 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
+    ws = ops.attn_launch_ws(q.device, is_causal, B * Hq * ((Lq + 127) // 128))      # (a large non-causal call: persistent launch)
     if v_scale is None:            # FP16 PV (v_image from prep_v_fp16), straight FP32 accumulation
         rc = _cabi.load().sage_attn_fused_q_pv_f16(
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
@@ -137,6 +138,7 @@ def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
+    ws = ops.attn_launch_ws(q.device, is_causal, B * Hq * ((Lq + 127) // 128))
     rc = _cabi.load().sage_attn_fused_qblock_pv_f16(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
@@ -387,6 +389,8 @@ def _varlen_attend(st: _VarlenState) -> torch.Tensor:
     plan = st.plan
     items, hdr, bound = (plan.items, plan.hdr, plan.items_bound) if plan is not None else (None, None, 0)
     nseq = st.cu_q.shape[0] - 1
+    # (a large non-causal call runs as a persistent launch; items = 128-row blocks of the packed rows, at least)
+    ws = ops.attn_launch_ws(q.device, st.is_causal, Hq * (q.shape[0] // 128)) if plan is not None else None
     if st.fuse_q:
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_ks), _p(st.order),

@@ -167,21 +167,100 @@ __device__ unsigned g_attn_trace[16 * kAttnTraceWgs];      // 16 words per workg
 // ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
-sage_attn_kernel(const AttnParams p)
+sage_attn_kernel(const AttnParams p_arg)
 {
+    // The parameter block is read through the kernarg segment pointer, and inside the persistent loop through a copy of that pointer the
+    // compiler cannot see through (an empty asm): otherwise every scalar load of a parameter is hoisted out of the loop and stays live in
+    // SGPRs across it (128 SGPRs and 16-400 VGPRs spilled in every instantiation).  AttnParams is the kernel's only explicit argument.
+    typedef const __attribute__((address_space(4))) AttnParams *kparams_t;
+    const kparams_t kp0 = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) AttnParams &p = *kp0;
+    (void)p_arg;
     using C = TileCfg<D, PV_FP8, NH>;
     constexpr int KT = C::KT;
     constexpr int NS = 2 * NH;                       // 32-key S^T sub-tiles per iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31;      // query row inside the wave's 32-row tile
-    const int g = lane >> 5;      // k-group (operand half)
+    // (wave index in an SGPR, lane index from v_mbcnt wherever it is needed: nothing derived from threadIdx.x has to stay in a VGPR across
+    //  the persistent loop below)
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #if SAGE_ATTN_TRACE
     __shared__ unsigned ttrace[16];
 #endif
+    // ---- persistent launch (p.sched != null; non-causal, unmasked instantiations only): gridDim.x workgroups -- as many as the device holds at
+    //      once -- work through the logical grid of p.nwg workgroup indices.  The indices are dealt into 32 queues: index i belongs to XCD i & 7
+    //      (the work order's L2 locality, sage_work_order.h) and there to sub-queue (i >> 3) & 3, i.e. i = 32 k + 8 s + x.  A workgroup starts with
+    //      its own blockIdx.x (the hardware deals blockIdx.x to XCD blockIdx.x & 7) and then takes tickets k from the counter of its queue -- the
+    //      ticket is requested behind the last tile of the item in hand and read after its output rows are on their way.  When that queue is empty
+    //      it looks at all 32 counters once and takes a ticket from the fullest queue, its own XCD's first (the XCDs of a device run a few per cent
+    //      apart: profiles/r4_run_p_attention_phase_trace.txt).  One counter per 128-byte line, zeroed by the caller: agent-scope atomics on one
+    //      address serialise at ~200 ns each, and the 64 workgroups of an XCD finish equal items together.
+    //      Causal launches keep the hardware's dispatch: their work order pairs a long and a short block on a CU through the order in which
+    //      freed slots are refilled, and tickets lose that (measured: +2.6 % at C3, +7 % at C2).
+    constexpr bool PERS_OK = !CAUSAL && MASK == 0;
+    const bool pers = PERS_OK && p.sched != nullptr;
+    __shared__ int s_ticket[2];                 // (two slots, alternating: a wave may still be reading the previous ticket when wave 0 posts the next)
+    int tpar = 0;
+    int bid = blockIdx.x;
+    int nwg_l = 0;                               // the logical grid
+    const int sched_first = gridDim.x >> 5;      // tickets of every queue that the first round (blockIdx.x) covers
+    const int my_xcd = pers ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;      // HW_REG_XCC_ID[3:0]
+    const int my_q = 4 * my_xcd + (int)((blockIdx.x >> 3) & 3u);
+    unsigned next_k_v = 0;                       // (lane 0 of wave 0) the ticket requested ahead
+    bool have_next = false, own_empty = false;   // wave-uniform
+    // wave 0: the next logical workgroup index, or -1 when every queue is empty
+    auto resolve_ticket = [&]() -> int {
+        if (have_next) {
+            have_next = false;
+            const int i = 32 * ((int)__builtin_amdgcn_readfirstlane(next_k_v) + sched_first) + 8 * (my_q & 3) + my_xcd;
+            if (i < nwg_l) return i;
+            own_empty = true;
+        }
+        int lane_o = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_o));         // (or the per-lane queue addresses below are computed once, outside the item loop, and stay live)
+        for (int attempt = 0; attempt < 4; attempt++) {
+            // lane q < 32 looks at queue q; the fullest queue wins, queues of the own XCD before the others
+            const int q = lane_o & 31, x = q >> 2, s8x = 8 * (q & 3) + x;
+            const unsigned c = lane_o < 32 ? __hip_atomic_load(p.sched + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const int cnt = nwg_l > s8x ? (nwg_l - s8x + 31) >> 5 : 0;
+            int left = cnt - sched_first - (int)c;
+            left = left < (1 << 24) ? left : (1 << 24) - 1;
+            unsigned key = (lane_o < 32 && left > 0) ? ((x == my_xcd ? 1u : 0u) << 30) | ((unsigned)left << 5) | (unsigned)q : 0u;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const unsigned o = __shfl_xor(key, m); key = o > key ? o : key; }
+            key = __builtin_amdgcn_readfirstlane(key);
+            if (key == 0u) return -1;
+            const int bq = (int)(key & 31u);
+            unsigned kv = 0;
+            if (lane_o == 0) kv = __hip_atomic_fetch_add(p.sched + 32 * bq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i = 32 * ((int)__builtin_amdgcn_readfirstlane(kv) + sched_first) + 8 * (bq & 3) + (bq >> 2);
+            if (i < nwg_l) return i;
+        }
+        return -1;
+    };
+    if (pers) {
+        nwg_l = p.nwg;
+        if (p.cu_q != nullptr && p.work_items != nullptr) {
+            typedef const __attribute__((address_space(4))) int *cint_p;
+            const cint_p hdr = (cint_p)p.work_hdr;
+            nwg_l = 8 * (hdr[3] * ((hdr[0] + 7) >> 3) + (p.Hq >> 3) * hdr[0]);
+        }
+    }
+    while (bid >= 0) {
+    next_k_v = 0;                                // (defined at the top of every pass: not carried round the loop in a VGPR)
+    do {
+    kparams_t kp = kp0;
+    if constexpr (PERS_OK) asm volatile("" : "+s"(kp));
+    const __attribute__((address_space(4))) AttnParams &p = *kp;
+    // (the same for everything derived from the thread index: hoisted out of the loop, the prologue's and the epilogue's per-lane
+    //  offsets would stay live through the key loop -- 13-32 VGPRs spilled in every instantiation)
+    int lane_v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (PERS_OK) asm volatile("" : "+v"(lane_v));
+    const int lane = lane_v;
+    const int wave = wave_s;
+    const int tid = wave * 64 + lane;
+    const int n = lane & 31;      // query row inside the wave's 32-row tile
+    const int g = lane >> 5;      // k-group (operand half)
     SAGE_TSTAMP(0);
 
     // ---- work item: XCD-aware, heavy-first --------------------------------------------------
@@ -197,7 +276,7 @@ sage_attn_kernel(const AttnParams p)
         const WorkOrder wo = {hdr[1], hdr[2], hdr[3]};
         const int nwg = 8 * (wo.left * ((nitems + 7) >> 3) + (p.Hq >> 3) * nitems);
         int qrank;
-        if ((int)blockIdx.x >= nwg || !work_item(wo, blockIdx.x, nwg, p.Hq, nitems, h, qrank)) return;
+        if (bid >= nwg || !work_item(wo, bid, nwg, p.Hq, nitems, h, qrank)) break;
         const cint_p items = (cint_p)p.work_items;
         b = items[2 * qrank];
         qblk = items[2 * qrank + 1];
@@ -207,11 +286,11 @@ sage_attn_kernel(const AttnParams p)
         // per XCD would hand one XCD the longest sequence
         // (measured 3.5x slower on lengths 256..16384).  XCDs take (sequence, kv-head) units round-robin instead;
         // inside a unit the `group` query heads that share the K/V stream run heavy-first, interleaved.
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int xcd = bid & 7, idx = bid >> 3;
         const int per_unit = nqblk * p.group;
         const int j = idx / per_unit, within = idx - j * per_unit;
         const int u = j * 8 + xcd;
-        if (u >= p.B * p.Hkv) return;
+        if (u >= p.B * p.Hkv) break;
         const int r = within / p.group, hg = within - r * p.group;
         qblk = nqblk - 1 - r;
         const int bs = u / p.Hkv;
@@ -226,7 +305,7 @@ sage_attn_kernel(const AttnParams p)
         // eight L2s; shortest-first order -5 %, alternating long/short -21 %.
         int bh, qrank;
         const WorkOrder wo = {CAUSAL ? p.order_group : 0, p.order_fold, p.order_left};      // causal work order: sage_work_order.h
-        if (!work_item(wo, blockIdx.x, gridDim.x, p.B * p.Hq, nqblk, bh, qrank)) return;
+        if (!work_item(wo, bid, pers ? p.nwg : (int)gridDim.x, p.B * p.Hq, nqblk, bh, qrank)) break;
         qblk = nqblk - 1 - qrank;
         b = bh / p.Hq;
         h = bh - b * p.Hq;
@@ -240,15 +319,15 @@ sage_attn_kernel(const AttnParams p)
     const float *qs_ptr, *ks_ptr;
     int qs_stride, ks_tstride;
     if (p.cu_q != nullptr) {              // varlen: packed [sum L, H, D]
-        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, requested together (as vector loads they
-        // were a memory round trip of their own behind the work list's; measured neutral at C4, profiles/r4_run_p_attention_phase_trace.txt)
+        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, all five requested together (as vector
+        // loads they were a second memory round trip behind the work list's, in front of the first tile's DMA)
         typedef const __attribute__((address_space(4))) int *cint_p;
         const int bu = __builtin_amdgcn_readfirstlane(b);
         const int q0 = ((cint_p)p.cu_q)[bu], k0 = ((cint_p)p.cu_k)[bu], q1 = ((cint_p)p.cu_q)[bu + 1], k1 = ((cint_p)p.cu_k)[bu + 1];
         const int ks0 = ((cint_p)p.cu_ks)[bu];
         Lq = q1 - q0;
         Lk = k1 - k0;
-        if (qblk * BLKQ >= Lq) return;
+        if (qblk * BLKQ >= Lq) break;
         q_off = (long)q0 * p.q_sl + (long)h * p.q_sh;
         k_off = (long)k0 * p.k_sl + (long)hk * p.k_sh;
         o_off = (long)q0 * p.o_sl + (long)h * p.o_sh;
@@ -1446,6 +1525,11 @@ sage_attn_kernel(const AttnParams p)
     SAGE_TSTAMP(4);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
     SAGE_TSTAMP(5);
+    // persistent launch: the next ticket is requested here, behind the last tile, and read after the output rows are on their way
+    if (pers && !own_empty) {
+        if (tid == 0) next_k_v = __hip_atomic_fetch_add(p.sched + 32 * my_q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        have_next = true;
+    }
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
     const float l_tot = pair_sum(l_run);
@@ -1523,20 +1607,32 @@ sage_attn_kernel(const AttnParams p)
     SAGE_TSTAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SAGE_TSTAMP(7);
-    if (wave == 0 && (int)blockIdx.x < kAttnTraceWgs) {
-        if (lane < 8) g_attn_trace[16 * blockIdx.x + lane] = ttrace[lane];
-        if (lane == 9) g_attn_trace[16 * blockIdx.x + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
-        if (lane == 10) g_attn_trace[16 * blockIdx.x + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        if (lane == 11) g_attn_trace[16 * blockIdx.x + 11] = blockIdx.x;
+    if (wave == 0 && bid < kAttnTraceWgs) {
+        if (lane < 8) g_attn_trace[16 * bid + lane] = ttrace[lane];
+        if (lane == 9) g_attn_trace[16 * bid + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        if (lane == 10) g_attn_trace[16 * bid + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        if (lane == 11) g_attn_trace[16 * bid + 11] = blockIdx.x;
     }
 #endif
+    } while (0);
+    if (!pers) break;
+    // (the barrier also separates this item's LDS transposes from the next item's first tiles)
+    if (wave_s == 0) { const int t = resolve_ticket(); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) s_ticket[tpar] = t; }
+    __syncthreads();
+    bid = __builtin_amdgcn_readfirstlane(s_ticket[tpar]);      // (wave-uniform: everything derived from it stays in SGPRs)
+    tpar ^= 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // One launch path for every instantiation: the > 64 KiB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize)
 // is issued once per instantiation and device, not per launch.
+constexpr int kPersistMinRounds = 12;
+static thread_local int g_last_attn_grid = 0;       // workgroups of this host thread's last attention launch (sage_debug_last_attn_grid: tests)
+int last_attn_grid() { return g_last_attn_grid; }
+
 template <typename Kern>
-static hipError_t launch_kernel(Kern kern, int lds, const AttnParams &p, int nwork, hipStream_t stream)
+static hipError_t launch_kernel(Kern kern, int lds, const AttnParams &p, int nwork, hipStream_t stream, bool persist_ok = false)
 {
     if (lds > 65536) {
         static thread_local unsigned long long done_mask = 0;      // bit per device ordinal (thread-local: no locking needed)
@@ -1550,7 +1646,37 @@ static hipError_t launch_kernel(Kern kern, int lds, const AttnParams &p, int nwo
             done_mask |= bit;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), lds, stream, p);
+    AttnParams pp = p;
+    int grid = nwork;
+    // Persistent launch (AttnParams::sched, a zeroed counter block of the caller; non-causal unmasked kernels): as many workgroups as the
+    // device holds at once take the logical workgroup indices 0 .. nwork - 1 from 32 ticket queues (see the kernel).  Worth it from twelve
+    // rounds of workgroups up -- one item must be small against the few per cent the XCDs differ by, or nothing can be evened out: with
+    // eight rounds of equal items (B2 H32 N8192 non-causal) the tickets cost 1 % -- anything else is an ordinary launch.
+    if (pp.sched != nullptr) {
+        unsigned *sched = pp.sched;
+        pp.sched = nullptr;
+        if (persist_ok && (nwork & 7) == 0) {
+            struct Occ { const void *k; int dev; int slots; };
+            static thread_local Occ cache[16];
+            static thread_local int ncache = 0;
+            int dev = 0, slots = -1;
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return e;
+            const void *kp = reinterpret_cast<const void *>(kern);
+            for (int c = 0; c < ncache; c++) if (cache[c].k == kp && cache[c].dev == dev) slots = cache[c].slots;
+            if (slots < 0) {
+                int ncu = 0, per_cu = 0;
+                e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, 256, lds);
+                if (e != hipSuccess) return e;
+                slots = ncu * per_cu;
+                if (ncache < 16) cache[ncache++] = Occ{kp, dev, slots};
+            }
+            if (slots > 0 && (slots & 31) == 0 && nwork >= kPersistMinRounds * slots) { pp.sched = sched; pp.nwg = nwork; grid = slots; }
+        }
+    }
+    g_last_attn_grid = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, pp);
     return hipGetLastError();
 }
 
@@ -1559,7 +1685,7 @@ static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
 {
     using C = TileCfg<D, PV_FP8, NH>;
     constexpr int lds = C::LDS_BYTES;
-    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>, lds, p, nwork, stream);
+    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>, lds, p, nwork, stream, !CAUSAL);
 }
 
 template <int D, bool PV_FP8, int NH>
@@ -1587,7 +1713,7 @@ static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t
     // FP8 PV: two-level accumulation; FP16 PV: straight FP32 accumulation (the entry points' defaults); tile shapes as launch_attn
     constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
     using C = TileCfg<D, PV_FP8, NH>;
-    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
+    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream, !CAUSAL);
 }
 
 // q in fp16 / bf16, quantised PER BLOCK in the prologue (QF 3 / 4): the Triton-named API's kernels (FP16 PV, per-block K scales,
@@ -1597,7 +1723,7 @@ static hipError_t launch_fused_qblock_one(const AttnParams &p, int nwork, hipStr
 {
     constexpr int NH = D == 64 ? SAGE_NH_F8 : 1;
     using C = TileCfg<D, false, NH>;
-    return launch_kernel(sage_attn_kernel<D, false, CAUSAL, false, true, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream);
+    return launch_kernel(sage_attn_kernel<D, false, CAUSAL, false, true, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream, !CAUSAL);
 }
 
 // Causal dense grids: which (head, query block) item a workgroup takes -- sage_work_order.h (mapping, group-size rule, measurements).

@@ -34,6 +34,15 @@ int check_launch(hipError_t e, const char *what)
 
 struct MaskArg { const void *ptr; int kind; int64_t sb, sh, sq, sk; };
 
+// The one-shot launch attribute of sage_attn_launch_ws: a zeroed counter block for the NEXT attention launch issued by this host thread.
+thread_local unsigned *g_launch_ws = nullptr;
+unsigned *take_launch_ws()
+{
+    unsigned *w = g_launch_ws;
+    g_launch_ws = nullptr;
+    return w;
+}
+
 int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
                 const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
                 const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_qs, const int32_t *cu_ks,
@@ -44,6 +53,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                 const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr,
                 const int32_t *work_items = nullptr, const int32_t *work_hdr = nullptr, int items_bound = 0)
 {
+    unsigned *const launch_ws = take_launch_ws();        // (consumed whatever happens below)
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d)", B, Hq, Hkv, Lq);
@@ -62,6 +72,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     SAGE_REQUIRE(!varlen || (cu_q && cu_k && cu_qs && cu_ks), "varlen needs cu_seqlens arrays");
 
     sage::AttnParams p{};
+    p.sched = launch_ws;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
@@ -550,6 +561,17 @@ SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t 
                          0.0f, dtype, 0, stream);
 }
 
+SAGE_API int64_t sage_attn_launch_ws_bytes(void) { return sage::kAttnSchedBytes; }
+SAGE_API int sage_debug_last_attn_grid(void) { return sage::last_attn_grid(); }
+
+SAGE_API int sage_attn_launch_ws(void *ws, int64_t bytes)
+{
+    SAGE_REQUIRE(ws == nullptr || (bytes >= sage::kAttnSchedBytes && (reinterpret_cast<uintptr_t>(ws) & 127u) == 0),
+                 "the launch workspace is %d bytes, 128-byte aligned, zeroed (got %lld bytes at %p)", sage::kAttnSchedBytes, (long long)bytes, ws);
+    g_launch_ws = static_cast<unsigned *>(ws);
+    return SAGE_OK;
+}
+
 SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
                             const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
                             int B, int Hq, int Hkv, int Lq, int Lk, int D,
@@ -612,6 +634,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream, bool pv_fp8 = true)
 {
+    unsigned *const launch_ws = take_launch_ws();
     SAGE_REQUIRE(q && k && v_image && o && k_scale && (v_scale || !pv_fp8), "null tensor pointer");
     SAGE_REQUIRE(kv_split >= 0 && (kv_split <= 1 || Hkv % kv_split == 0), "kv_split (%d) must divide the folded kv-head count (%d)", kv_split, Hkv);
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -624,6 +647,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
     SAGE_REQUIRE(k_sl % 16 == 0 && k_sh % 16 == 0 && k_sb % 16 == 0, "int8 k strides must be multiples of 16");
     SAGE_REQUIRE(o_sl % 8 == 0 && o_sh % 8 == 0 && o_sb % 8 == 0, "output strides must be multiples of 8 elements");
     sage::AttnParams p{};
+    p.sched = launch_ws;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
@@ -673,6 +697,7 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
                                int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
 {
+    unsigned *const launch_ws = take_launch_ws();
     const bool varlen = cu_q != nullptr;
     SAGE_REQUIRE(q && k && v_image && o && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -687,6 +712,7 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
     SAGE_REQUIRE(!varlen || (cu_k && cu_ks), "varlen needs cu_seqlens_k and the k scale prefix array");
     SAGE_REQUIRE(!varlen || lse == nullptr, "varlen returns no lse");
     sage::AttnParams p{};
+    p.sched = launch_ws;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.k_scale = k_scale;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = nullptr; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
@@ -739,6 +765,7 @@ SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
 {
+    (void)take_launch_ws();                              // split launches take no launch workspace
     SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
     SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
     SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);
@@ -753,6 +780,7 @@ SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, cons
                                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                             int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
 {
+    (void)take_launch_ws();                              // split launches take no launch workspace
     SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
     SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
     SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);

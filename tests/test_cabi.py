@@ -77,6 +77,26 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1
 
 
+def test_launch_workspace_attribute_is_checked_and_one_shot():
+    """sage_attn_launch_ws: size and alignment are checked; the attribute is consumed by the next attention call of the thread even when
+    that call fails its argument checks (no launch, no GPU needed): the call after it must not see it."""
+    lib = _cabi.load()
+    n = int(lib.sage_attn_launch_ws_bytes())
+    assert n == 32 * 128
+    buf = ctypes.create_string_buffer(n + 256)
+    p = (ctypes.addressof(buf) + 127) & ~127
+    assert lib.sage_attn_launch_ws(p, n - 1) == -1 and b"launch workspace" in lib.sage_last_error()
+    assert lib.sage_attn_launch_ws(p + 64, n) == -1
+    assert lib.sage_attn_launch_ws(None, 0) == 0
+    assert lib.sage_attn_launch_ws(p, n) == 0
+    # a failing attention call (Hq not divisible by Hkv) consumes it ...
+    rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None)
+    assert rc == -1
+    # ... (the library offers no getter: the attribute is write-only by design; that it is gone is checked on the GPU, where a launch
+    # without a fresh attribute must be an ordinary one -- tests/test_gpu_parity.py)
+    assert lib.sage_attn_launch_ws(None, 0) == 0
+
+
 def test_v_image_bytes():
     lib = _cabi.load()
     assert lib.sage_v_image_bytes(128, 1, 10) == 10 * 128 * 64

@@ -1258,6 +1258,56 @@ def test_varlen_with_empty_sequences(causal):
         assert (o[128:428] == 0).all() and (o[:128] != 0).any()
 
 
+def test_persistent_launches_are_bit_identical_and_really_taken(monkeypatch):
+    """Large non-causal calls hand the attention launch a zeroed counter block (sage_attn_launch_ws) and run as persistent launches: fewer
+    workgroups than work items, the same output bits as the ordinary launch; causal calls and small calls stay ordinary launches; the
+    attribute does not outlive the call it was set for."""
+    from sageattention_amd import ops
+    lib = sq._cabi.load()
+    g = torch.Generator().manual_seed(77)
+
+    def run(fn, on):
+        monkeypatch.setattr(ops, "_PERSISTENT", on)
+        out = fn()
+        torch.cuda.synchronize()
+        return out, int(lib.sage_debug_last_attn_grid())
+
+    # dense, FP8 PV (sageattn) at D = 64 (three workgroups per CU: 768 at once) and D = 128 (512), FP16 PV and the Triton-named API:
+    # twelve rounds of workgroups = 2 * 36 * 128 = 9216 / 2 * 24 * 128 = 6144 work items
+    for D, H, api in ((64, 36, sa.sageattn), (128, 24, sa.sageattn), (128, 24, sa.sageattn_qk_int8_pv_fp16_cuda),
+                      (128, 24, sa.sageattn_qk_int8_pv_fp16_triton)):
+        q, k, v = (torch.randn(2, H, 16384, D, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3))
+        o1, g1 = run(lambda: api(q, k, v, is_causal=False), True)
+        o0, g0 = run(lambda: api(q, k, v, is_causal=False), False)
+        assert g0 == 2 * H * 128 and 0 < g1 < g0 and g1 % 32 == 0, (api.__name__, D, g0, g1)
+        assert torch.equal(o1, o0), (api.__name__, D)
+        del o1, o0
+        qc, kc, vc = q[:, :, :4096].contiguous(), k[:, :, :4096].contiguous(), v[:, :, :4096].contiguous()
+        _, gc = run(lambda: api(qc, kc, vc, is_causal=True), True)            # causal: the hardware's dispatch
+        assert gc >= 2 * H * 32
+        _, gs = run(lambda: api(qc, kc, vc, is_causal=False), True)           # eight rounds at most: an ordinary launch
+        assert gs == 2 * H * 32
+        del q, k, v, qc, kc, vc
+    # a launch without a fresh attribute is an ordinary one (the attribute of the previous call was consumed by it)
+    q, k, v = (torch.randn(2, 24, 16384, 128, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3))
+    _, g1 = run(lambda: sa.sageattn(q, k, v), True)
+    monkeypatch.setattr(ops, "attn_launch_ws", lambda *a, **kw: None)
+    o0 = sa.sageattn(q, k, v)
+    torch.cuda.synchronize()
+    assert int(lib.sage_debug_last_attn_grid()) == 6144 and g1 < 6144
+    monkeypatch.undo()
+    del q, k, v, o0
+    # packed batches, non-causal: 16 heads x 52000 rows
+    lens = [19000, 300, 17000, 129, 15571]
+    q = torch.randn(sum(lens), 16, 128, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(sum(lens), 4, 128, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(sum(lens), 4, 128, generator=g).to(torch.bfloat16).to(DEV)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    o1, g1 = run(lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens)), True)
+    o0, g0 = run(lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens)), False)
+    assert 0 < g1 < g0 and torch.equal(o1, o0)
+
+
 def test_varlen_with_more_sequences_than_the_plan_takes(oracle_mod):
     """More than sage_varlen_plan_max_seqs() sequences: no plan, so torch prefix sums, an on-device argsort for the unit order, the kernel
     sequence, the Q quantiser fused in the attention prologue -- exercised end to end (round 3 only checked that the planner returns None).
