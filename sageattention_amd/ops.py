@@ -36,7 +36,8 @@ def _lse_alloc(query: torch.Tensor, tensor_layout: int, return_lse: int) -> torc
 
 
 _PERSISTENT = os.environ.get("SAGE_PERSISTENT_LAUNCH", "1") != "0"      # 0: every attention launch leaves its order to the hardware
-_PERSISTENT_MIN_ITEMS = 6144       # twelve rounds of the 512 workgroups an MI355X holds (the library decides; this only spares smaller calls the memset)
+# twelve rounds of the 512 workgroups an MI355X holds (the library decides; this only spares smaller calls the memset)
+_PERSISTENT_MIN_ITEMS = 6144
 
 
 def attn_launch_ws(device: torch.device, is_causal, n_items: int) -> Optional[torch.Tensor]:
