@@ -141,3 +141,27 @@ def test_c4_work_list_shape():
     its, (nitems, grp, fold, left), grid = varlen_items(lens, lens, True, 32, 8)
     assert nitems == 262 and grid == 8 * 4 * 262 and left == 0 and grp == 4 and fold == 0
     assert its[0] == (7, 127) and its[1] == (7, 126)
+
+
+def test_ticket_queues_of_the_persistent_launch_partition_the_logical_grid():
+    """The persistent launch (csrc/sage_attn.hip, `PERS_OK` kernels) deals the logical workgroup indices 0 .. nwg - 1 into 32 queues: index
+    i = 32 k + 8 s + x belongs to XCD x = i & 7 (the work order's locality) and sub-queue s = (i >> 3) & 3, ticket k.  Restated here: the queues
+    partition the grid for every nwg (also one that is no multiple of 32), the count formula the kernel uses for "how much is left" is the size
+    of the queue, and the first round -- a launch of G workgroups, G a multiple of 32, takes i = blockIdx.x without a ticket -- is exactly the
+    tickets k < G / 32 of every queue, so that the counters can start at zero."""
+    for nwg in (8, 24, 32, 40, 512, 6144, 8384, 13344, 13344 + 8):
+        seen = []
+        for q in range(32):
+            x, s = q >> 2, q & 3
+            s8x = 8 * s + x
+            cnt = (nwg - s8x + 31) >> 5 if nwg > s8x else 0            # the kernel's formula
+            idx = [32 * k + s8x for k in range(cnt + 2) if 32 * k + s8x < nwg]
+            assert len(idx) == cnt, (nwg, q)
+            assert all((i & 7) == x and ((i >> 3) & 3) == s for i in idx)
+            seen += idx
+        assert sorted(seen) == list(range(nwg))
+    for G in (512, 768):
+        first = G >> 5
+        for q in range(32):
+            s8x = 8 * (q & 3) + (q >> 2)
+            assert all(32 * k + s8x < G for k in range(first)) and 32 * first + s8x >= G
