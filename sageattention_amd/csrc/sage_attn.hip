@@ -319,8 +319,8 @@ sage_attn_kernel(const AttnParams p_arg)
     const float *qs_ptr, *ks_ptr;
     int qs_stride, ks_tstride;
     if (p.cu_q != nullptr) {              // varlen: packed [sum L, H, D]
-        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, all five requested together (as vector
-        // loads they were a second memory round trip behind the work list's, in front of the first tile's DMA)
+        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, requested together (as vector loads they
+        // were a memory round trip of their own behind the work list's; measured neutral at C4, profiles/r4_run_p_attention_phase_trace.txt)
         typedef const __attribute__((address_space(4))) int *cint_p;
         const int bu = __builtin_amdgcn_readfirstlane(b);
         const int q0 = ((cint_p)p.cu_q)[bu], k0 = ((cint_p)p.cu_k)[bu], q1 = ((cint_p)p.cu_q)[bu + 1], k1 = ((cint_p)p.cu_k)[bu + 1];
