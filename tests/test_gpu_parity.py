@@ -1352,13 +1352,17 @@ def test_graphed_sageattn_replays_bit_identically_and_cuts_host_time():
     want_o, want_lse = sa.sageattn(q2, k2, v2, is_causal=True, return_lse=True)
     torch.cuda.synchronize()
     assert torch.equal(o, want_o) and torch.equal(lse, want_lse)
-    def host_us(fn, n=200):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        dt = time.perf_counter() - t0
+    def host_us(fn, n=40, batches=6):
+        # the best of several short batches: a batch that runs into a full queue (the host then waits for the GPU) or into a busy host
+        # measures something else -- one 200-call batch per route failed on a slow box (graphed 282 us against 25 us on every other box)
+        best = float("inf")
+        for _ in range(batches):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            best = min(best, (time.perf_counter() - t0) / n * 1e6)
         torch.cuda.synchronize()
-        return dt / n * 1e6
+        return best
     eager, graphed = host_us(lambda: sa.sageattn(q2, k2, v2, is_causal=True, return_lse=True)), host_us(ga.replay)
     REPORT["graph/host_us_per_call"] = dict(eager=eager, graphed=graphed)
     assert graphed < eager
