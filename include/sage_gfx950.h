@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 18
+#define SAGE_ABI_VERSION 19
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -264,21 +264,45 @@ SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t 
                            int64_t v_sl, int64_t v_sh, int dtype, void *stream);
 
 /*
- * Launch workspace of the attention entry points below (optional, a gfx950 launch attribute; the reference has no counterpart: its
- * kernels leave the order of their thread blocks to the hardware, qk_int_sv_f8_cuda_sm89.cuh:720-738).
- * sage_attn_launch_ws(ws, bytes) hands the NEXT attention launch issued by THIS host thread a block of device memory of
- * sage_attn_launch_ws_bytes() bytes, 128-byte aligned, ZEROED by the caller in stream order in front of that launch.  It is a one-shot
- * attribute, held in a thread-local word: the next sage_attn_* call of the thread consumes it whether it uses it or not (argument
- * errors included); NULL clears it.  With it a NON-CAUSAL, unmasked launch of at least twelve rounds of workgroups runs as a persistent
- * launch -- as many workgroups as the device holds at once take the work items as tickets from 32 queues (4 per XCD, own XCD first: the
- * L2 locality of the work order; then the fullest other queue: the XCDs of a device run a few per cent apart) -- which measured 2.2-2.4 %
- * faster on the CogVideoX shape and on packed batches (profiles/r4_run_p_attention_phase_trace.txt); every other launch ignores it.
- * Results do not depend on it.  The block must stay untouched until the launch has finished and may be reused (zeroed again) afterwards.
+ * Launch attributes of the attention entry points below: every sage_attn_* function takes a trailing `const SageLaunchAttr *attr`
+ * (NULL = all defaults).  The attributes are ARGUMENTS of the call they travel with -- the library keeps nothing between calls (ABI 18's
+ * thread-local sage_attn_launch_ws setter is gone).  The reference has no counterpart: its kernels leave the order of their thread blocks
+ * to the hardware (qk_int_sv_f8_cuda_sm89.cuh:720-738) and have one score form.  Results do not depend on launch_ws / flags bit 1.
+ *
+ *  struct_bytes     sizeof(SageLaunchAttr) as the caller compiled it (fields past it read as zero; 0 is taken as the full struct)
+ *  flags            SAGE_ATTR_* below
+ *  launch_ws        nullable: sage_attn_launch_ws_bytes() bytes of device memory, 128-byte aligned, ZEROED by the caller in stream order in
+ *                   front of this launch, untouched until the launch has finished (then reusable, zeroed again).  With it a NON-CAUSAL,
+ *                   unmasked launch of at least twelve rounds of workgroups runs as a persistent launch: as many workgroups as the device
+ *                   holds at once take the work items as tickets from 32 queues (4 per XCD, own XCD first: the L2 locality of the work
+ *                   order; then the fullest other queue: the XCDs of a device run a few per cent apart) -- 2.2-2.8 % faster on the CogVideoX
+ *                   shape and on packed batches (profiles/r4_run_p_attention_phase_trace.txt).  Every other launch ignores it (masked and
+ *                   split-KV entry points always).  A block that is NOT zero makes the launch skip work items: the contract is the caller's.
+ *  launch_ws_bytes  size of that block (checked)
+ *  grid_out         nullable HOST pointer: receives the number of workgroups launched (a persistent launch has fewer than work items)
+ *  trace, trace_wgs debug: read by -DSAGE_ATTN_TRACE=1 builds only (tools/attn_trace.py); 16 words per logical workgroup
  */
+typedef struct SageLaunchAttr {
+    uint32_t struct_bytes;
+    uint32_t flags;
+    void *launch_ws;
+    int64_t launch_ws_bytes;
+    int32_t *grid_out;
+    uint32_t *trace;
+    int32_t trace_wgs;
+    int32_t reserved;
+} SageLaunchAttr;
+/* FP8 PV only.  The softmax argument of a score is fma(s, c, -m) with s the INT32 dot product, c the dequantisation scale in the log2
+ * domain and m the running row maximum (attn_utils.cuh:445-449).  The kernels read the accumulator's bit pattern as the float
+ * bias + s * 2^-26 (bias = 0x3E22F983 as a float, exact).  Default ("folded"): one FMA per score, fma(bits, c', -(m + bias * c')) with
+ * m + bias * c' rounded once per (row, 64-key tile, k scale) -- up to 0.64 of one INT8 x INT8 score step of error in the exponent, which
+ * re-rolls a few e4m3 roundings of P per row (statistically the same result; measured against the exact form: DESIGN.md 4).  With this
+ * flag ("exact"): the bias is subtracted first (exact, Sterbenz), then the FMA -- bit for bit the reference's formula, 3-7 % slower.
+ * The oracle has both forms (oracle/sage_oracle.c score_mode); each form is held to 2e-3 * max|o| against its own. */
+#define SAGE_ATTR_FP8_EXACT_SCORES 1u
+/* tests: take the persistent route from two rounds of workgroups up instead of twelve (needs launch_ws) */
+#define SAGE_ATTR_FORCE_PERSISTENT 2u
 SAGE_API int64_t sage_attn_launch_ws_bytes(void);
-SAGE_API int sage_attn_launch_ws(void *ws, int64_t bytes);
-/* The number of workgroups of this host thread's last attention launch (a persistent launch has fewer than work items): for tests. */
-SAGE_API int sage_debug_last_attn_grid(void);
 
 /*
  * Fused attention, INT8 QK^T + FP8 PV.
@@ -303,7 +327,7 @@ SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const voi
                             int64_t k_sb, int64_t k_sh, int64_t k_sl,
                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
                             int is_causal, int qk_quant_gran, int q_warp,
-                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream);
+                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* Fused attention, INT8 QK^T + FP16 PV (FP32 accumulate).
  * Replaces: qk_int8_sv_f16_accum_f32_attn, _accum_f16_attn, _accum_f16_attn_inst_buf,
@@ -316,7 +340,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const vo
                              int64_t k_sb, int64_t k_sh, int64_t k_sl,
                              int64_t o_sb, int64_t o_sh, int64_t o_sl,
                              int is_causal, int qk_quant_gran, int q_warp,
-                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream);
+                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* attn_mask kinds of sage_attn_qk_int8_pv_f16_masked */
 #define SAGE_MASK_BOOL 1      /* 1 byte per element, non-zero = attend           */
@@ -337,7 +361,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
                                     int64_t q_sb, int64_t q_sh, int64_t q_sl,
                                     int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                     int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                    float sm_scale_log2, int out_dtype, void *stream);
+                                    float sm_scale_log2, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* Variable-length fused attention (per-block scales, FP16 PV), packed q/o [sum Lq, Hq, D],
  * k [sum Lk, Hkv, D].  Replaces: attn_qk_int8_block_varlen.py:123, _causal_varlen.py:125.
@@ -356,7 +380,7 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh,
                                     int64_t o_sl, int64_t o_sh,
                                     int is_causal, float sm_scale_log2, int pv_accum, int out_dtype,
-                                    void *stream);
+                                    void *stream, const SageLaunchAttr *attr);
 
 /* FP8-PV attention (two-level accumulation, "per-thread" granularity) with the Q quantisation fused into the kernel:
  * q is the fp16 / bf16 query tensor itself (element strides); each workgroup quantises its 128 rows in registers with
@@ -370,7 +394,7 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
                                      int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                      int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* FP16-PV attention (FP32 accumulation, "per-thread" granularity) with the same fused Q quantisation: bit-identical to
  * sage_quant_qk_int8 + sage_attn_qk_int8_pv_f16(pv_accum = single).  v_image from sage_prep_v_f16; v_mean nullable [B,Hkv,D].
@@ -380,7 +404,7 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                                       int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                       int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* The Triton-named API's attention (FP16 PV, tile product folded into the FP32 output, per-block k scales) with the PER-BLOCK Q
  * quantisation in the kernel prologue: q (fp16 / bf16) is multiplied by q_premul (= sm_scale * log2 e), one scale per 128 query rows,
@@ -391,7 +415,7 @@ SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const
                                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream);
+                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 /* The packed / varlen form (sage_attn_qk_int8_pv_f16_varlen's operands without q_scale / cu_q_scale; q in fp16 / bf16).
  * Replaces: quant_per_block_varlen.py:60-104 (the q half, core.py:436-439) + attn_qk_int8_block_varlen.py forward. */
 SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
@@ -399,7 +423,7 @@ SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k
                                                   const int32_t *seq_order, const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                                   int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                                   int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
-                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream);
+                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* The same kernel over a key range split into kv_split chunks of Lk_chunk keys each (a whole number of 64-key tiles), folded
  * into the kv-head dimension: k / k_scale / v_image / v_scale / v_mean are the operands of the unsplit call viewed as
@@ -413,14 +437,14 @@ SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const
                                            int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 /* The FP16-PV counterpart (sage_attn_fused_q_pv_f16 over a split key range; v_image is the fp16 image, no v_scale). */
 SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
                                             const float *k_scale, const float *v_mean,
                                             int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
                                             int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream);
+                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* Merge a partial attention state into a running FP32 state by log-sum-exp (natural log), in place:
  *   m = max(lse_acc, lse_new); w_a = e^(lse_acc-m); w_b = e^(lse_new-m);

@@ -26,6 +26,7 @@ LOG2E = 1.44269504  # the literal the reference uses (quant_per_block.py:87)
 F16, BF16 = 0, 1
 STYLE_TRITON, STYLE_CUDA, STYLE_TRITON_THREAD = 0, 1, 2
 PV_F16_TRITON, PV_F16_F32ACC, PV_F8_TWO_LEVEL, PV_F8_SINGLE = 0, 1, 2, 3
+SCORES_EXACT, SCORES_FOLDED = 0, 1      # FP8 PV: the form of the softmax argument (sage_oracle.c, score_mode)
 
 
 def build(force: bool = False) -> str:
@@ -138,8 +139,9 @@ def v_mean_padded16(v: np.ndarray, dtype: int) -> np.ndarray:
 
 
 def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float, pv_mode: int,
-         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False, mask_bool=None, mask_add=None):
-    """Fused attention on quantised operands; returns (o bits uint16 [B,Hq,Lq,D], lse|None)."""
+         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False, mask_bool=None, mask_add=None, score_mode: int = SCORES_EXACT):
+    """Fused attention on quantised operands; returns (o bits uint16 [B,Hq,Lq,D], lse|None).  ``score_mode`` (FP8 modes): SCORES_EXACT
+    = the reference's formula, SCORES_FOLDED = the reassociation the gfx950 kernels' default FP8 loops evaluate (sage_oracle.c)."""
     B, Hq, Lq, D = q8.shape
     _, Hkv, Lk, _ = k8.shape
     o = np.empty((B, Hq, Lq, D), dtype=np.uint16)
@@ -153,7 +155,7 @@ def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float,
                         _p(None if mask_bool is None else np.ascontiguousarray(np.broadcast_to(mask_bool, (B, Hq, Lq, Lk)), dtype=np.uint8)),
                         _p(None if mask_add is None else np.ascontiguousarray(np.broadcast_to(mask_add, (B, Hq, Lq, Lk)), dtype=np.float32)),
                         int(B), int(Hq), int(Hkv), int(Lq), int(Lk), int(D), int(causal),
-                        ctypes.c_float(float(c)), int(pv_mode), int(out_dtype))
+                        ctypes.c_float(float(c)), int(pv_mode), int(out_dtype), int(score_mode))
     assert rc == 0, "orc_attn rejected the arguments"
     return o, lse
 
@@ -181,7 +183,7 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
                    qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32,
-                   smooth_v=False, vm=None, mask_bool=None, mask_add=None, blkk=64):
+                   smooth_v=False, vm=None, mask_bool=None, mask_add=None, blkk=64, fp8_scores="exact", single_level=False):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -189,6 +191,8 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
     pv "f8": sageattn_qk_int8_pv_fp8_cuda (core.py:636-826) with fp32+fp32 two-level
         accumulation; qk_quant_gran per_warp | per_thread (| per_block, our extension).
     pv "f16": sageattn_qk_int8_pv_fp16_cuda pv_accum_dtype="fp32" (core.py:451-633).
+    fp8_scores ("exact" | "folded", pv "f8" only): the form of the softmax argument, see ``attn`` (the product's default is "folded").
+    single_level (pv "f8"): pv_accum_dtype="fp32", every tile accumulated straight into the output.
     warpq / blkk: scale-group sizes of the CUDA-named APIs -- WARPQ 32, or 16 for head_dim 128 with
         "fp16+fp32" (core.py:602-604); the sm90 entry point uses WARPQ 16 and BLKK = WARPK = 128 (core.py:964-970).
     Returns (o bits [B,Hq,Lq,D0], lse or None, aux dict of intermediates).
@@ -235,8 +239,9 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
             vm = v_mean_padded16(v, dtype)
         v8, vs = quant_v_fp8(v, dtype, mean=vm if smooth_v else None)
         aux.update(v8=v8, vs=vs, vm=vm)
-        o, lse = attn(q8, k8, v8, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=PV_F8_TWO_LEVEL,
-                      out_dtype=dtype, v_scale=vs, v_mean=vm if smooth_v else None, return_lse=return_lse)
+        o, lse = attn(q8, k8, v8, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=PV_F8_SINGLE if single_level else PV_F8_TWO_LEVEL,
+                      out_dtype=dtype, v_scale=vs, v_mean=vm if smooth_v else None, return_lse=return_lse,
+                      score_mode={"exact": SCORES_EXACT, "folded": SCORES_FOLDED}[fp8_scores])
     else:
         mode = PV_F16_TRITON if pv == "f16_triton" else PV_F16_F32ACC
         if smooth_v:   # sub_mean (quant.py:182-222): vm = v.mean(seq) in the input dtype, (v - vm) -> fp16

@@ -285,6 +285,19 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  * Tiles: 128 query rows x 64 keys (attn_qk_int8_per_block.py:131-132).
  * lse (nullable) [B,Hq,Lq] = log2(l) + m, log2 units (attn_qk_int8_per_block.py:126-127).
  * out dtype: 0 fp16, 1 bf16.
+ * score_mode (FP8 modes 2 / 3 only; 0 everywhere else):
+ *   0 "exact":  P = exp2(fma(raw score, sm_scale', -m)), the reference's formula (attn_utils.cuh:445-449) -- the mode that is pinned to
+ *               the reference text and that the gfx950 kernels run under SAGE_ATTR_FP8_EXACT_SCORES.
+ *   1 "folded": the SAME formula reassociated as the gfx950 kernels' default FP8 loops evaluate it.  They read the INT32 accumulator,
+ *               which starts from the bit pattern 0x3E22F983 (the float 1/(2 pi)), as the float  x = bias + s * 2^-26  (exact for
+ *               |s| <= 2^21) and form, with c' = sm_scale' * 2^26 (a power-of-two scaling: exact),
+ *                   mb = fma(bias, c', m)          rounded ONCE per (row, 64-key tile, k scale)
+ *                   P  = exp2(fma(x, c', -mb))     one rounding
+ *               Real-number value: s * sm_scale' - m - delta, delta = the rounding of mb (<= half an ulp of |bias * c' + m|): up to
+ *               ~0.6 of one INT8 x INT8 score step in the exponent.  The row maximum m itself is formed as in mode 0 (from the exact
+ *               integer maximum), in both kernels.  This mode mirrors that rounding for rounding so that the kernel can be held to
+ *               2e-3 * max|o| against it; how far it is from mode 0 is a property of the arithmetic, measured on the CPU
+ *               (tests/test_oracle_golden.py::test_folded_scores_vs_exact).
  * mask_b / mask_f (at most one non-NULL, [B,Hq,Lq,Lk], non-causal only): attn_mask of the Triton path
  *   (attn_qk_int8_per_block.py:31-51).  bool: a 128x64 tile whose mask block is all False is skipped
  *   (:36-38), otherwise 0 / -1e6 is added to the score (:47-48); float: the value is added (:49-50);
@@ -300,9 +313,11 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         const float *v_scale, const float *v_mean,
                         const uint8_t *mask_b, const float *mask_f,
                         int B, int Hq, int Hkv, int Lq, int Lk, int D,
-                        int causal, float c, int pv_mode, int out_dtype)
+                        int causal, float c, int pv_mode, int out_dtype, int score_mode)
 {
     if (D > 128 || Hq % Hkv) return -1;
+    if (score_mode != 0 && (score_mode != 1 || pv_mode < 2 || mask_b || mask_f)) return -1;
+    const float bias = bits_f(0x3E22F983u);          /* 1 / (2 pi) as the kernels' MFMA C operand */
     const int g = Hq / Hkv;
     const int nqb = (Lq + BM - 1) / BM;
     const int fp8 = pv_mode >= 2;
@@ -350,6 +365,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         const float qsc = qs[q_sidx[r0 + i]];
                         float mx = NEG_BIG;       /* non-fused: max score; fused: max of (score - offset) */
                         float dotf[BN], ccj[BN];
+                        int32_t doti[BN];
                         /* pv_mode 0 restates the Triton kernel literally: qk = dot * (q_scale*k_scale), then
                          * qk - m (attn_qk_int8_per_block.py:41,53-55).  The other modes restate the CUDA kernels:
                          *   dequant_scale = q_scale * k_scale;  sm_scale' = (sm_scale*log2e) * dequant_scale
@@ -367,6 +383,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                                 const int8_t *kr = kp + (size_t)(n0 + j) * D;
                                 int32_t dot = 0;
                                 for (int d = 0; d < D; d++) dot += (int32_t)qr[d] * (int32_t)kr[d];
+                                doti[j] = dot;
                                 if (fused) {
                                     dotf[j] = (float)dot;
                                     ccj[j] = c * (qsc * ks[k_sidx[n0 + j]]);
@@ -386,6 +403,12 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         for (int j = 0; j < BN; j++) {
                             float e;
                             if (p[i][j] <= NEG_BIG) e = 0.0f;
+                            else if (fused && score_mode == 1) {
+                                const float c26 = ccj[j] * 67108864.0f;                       /* c' = sm_scale' * 2^26 */
+                                const float x = bits_f(0x3E22F983u + (uint32_t)doti[j]);       /* bias + s * 2^-26, exact */
+                                const float mb = fmaf(bias, c26, m_new);
+                                e = exp2f(fmaf(x, c26, -mb));
+                            }
                             else if (fused) e = exp2f(fmaf(dotf[j], ccj[j], -m_new));
                             else e = exp2f(p[i][j] - m_new);
                             p[i][j] = fp8 ? orc_e4m3_2f(orc_f2e4m3(e)) : orc_h2f(orc_f2h(e));
@@ -434,4 +457,4 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
     return 0;
 }
 
-ORC_EXPORT int orc_version(void) { return 1; }
+ORC_EXPORT int orc_version(void) { return 2; }

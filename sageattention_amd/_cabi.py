@@ -15,17 +15,50 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 18
+ABI_VERSION = 19
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
 QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
 PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL, PV_ACCUM_TRITON = 0, 1, 2   # 2: FP16 PV, the reference's Triton kernel form
 MASK_BOOL, MASK_F16, MASK_BF16 = 1, 2, 3
+ATTR_FP8_EXACT_SCORES, ATTR_FORCE_PERSISTENT = 1, 2
+
+
+class SageLaunchAttr(ctypes.Structure):
+    """``SageLaunchAttr`` of include/sage_gfx950.h: the launch attributes an attention entry point takes as its last argument."""
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("launch_ws", c_void_p), ("launch_ws_bytes", c_int64),
+                ("grid_out", c_void_p), ("trace", c_void_p), ("trace_wgs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def launch_attr(launch_ws=None, exact_scores: bool = False, force_persistent: bool = False, grid_out=None, trace=None, trace_wgs: int = 0):
+    """A ``SageLaunchAttr`` (or None when every field is at its default).  ``launch_ws``: a zeroed int32 CUDA tensor of
+    ``sage_attn_launch_ws_bytes()`` bytes; the caller keeps it (and the returned struct) alive until the C call has returned.
+    ``grid_out``: a ``ctypes.c_int32`` that receives the number of workgroups launched."""
+    if launch_ws is None and not exact_scores and grid_out is None and trace is None:
+        return None
+    a = SageLaunchAttr()
+    a.struct_bytes = ctypes.sizeof(SageLaunchAttr)
+    a.flags = (ATTR_FP8_EXACT_SCORES if exact_scores else 0) | (ATTR_FORCE_PERSISTENT if force_persistent else 0)
+    if launch_ws is not None:
+        a.launch_ws = launch_ws.data_ptr()
+        a.launch_ws_bytes = launch_ws.numel() * launch_ws.element_size()
+    if grid_out is not None:
+        a.grid_out = ctypes.addressof(grid_out)
+    if trace is not None:
+        a.trace = trace.data_ptr()
+        a.trace_wgs = int(trace_wgs)
+    a._keep = (launch_ws, grid_out, trace)      # (the struct holds raw addresses)
+    return a
+
+
+def attr_arg(a):
+    """The ``attr`` argument of an attention entry point: NULL or a pointer to the struct."""
+    return None if a is None else ctypes.byref(a)
 
 # every symbol include/sage_gfx950.h declares: name -> (restype, argtypes)
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
-SYMBOLS = {
+SYMBOLS = {   # (the trailing _P of every sage_attn_* entry point is `const SageLaunchAttr *attr`, nullable)
     "sage_abi_version": (c_int, []),
     "sage_last_error": (ctypes.c_char_p, []),
     "sage_debug_work_order_plan": (c_int, [_I, _I, _L, _I, _I, _I, _P, _P, _P]),
@@ -57,31 +90,29 @@ SYMBOLS = {
     "sage_prep_v_f16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
     "sage_prep_v_f16_varlen": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P]),
     "sage_attn_launch_ws_bytes": (c_int64, []),
-    "sage_attn_launch_ws": (c_int, [_P, _L]),
-    "sage_debug_last_attn_grid": (c_int, []),
     "sage_attn_qk_int8_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P]),
+                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I,
-                                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P]),
+                                                _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                                _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                                _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_q_pv_f8": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                        _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_q_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_varlen_plan_max_seqs": (c_int, []),
     "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sage_debug_varlen_items": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sage_attn_fused_qblock_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                              _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                              _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_qblock_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
-                                                     _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                                     _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_q_pv_f8_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
-                                              _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                              _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_q_pv_f16_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
-                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P]),
+                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_merge_states": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _P]),
     "sage_merge_split": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _P]),
 }

@@ -75,7 +75,7 @@ def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
 
 
 def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dtype, tensor_layout, is_causal,
-                gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None):
+                gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None, exact_scores=False):
     """Allocate ``o`` and launch the fused kernel through the registered custom op (-> C ABI)."""
     B, Hq, Lq, D, _, _, _ = _dims(q_int8, tensor_layout)
     Hkv = _dims(k_int8, tensor_layout)[1]
@@ -91,7 +91,7 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     f16 = ops.qk_int8_sv_f16_attn if compiling else ops.qk_int8_sv_f16_attn_impl
     if fp8:
         lse = f8(q_int8, k_int8, v_image, o, q_scale, k_scale, v_scale, v_mean, layout, int(is_causal),
-                 gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
+                 gran, q_warp, float(sm_scale_log2), accum, int(return_lse), bool(exact_scores))
     else:
         lse = f16(q_int8, k_int8, v_image, o, q_scale, k_scale, v_mean, layout, int(is_causal),
                   gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
@@ -99,7 +99,7 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
 
 
 @torch.compiler.disable
-def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None):
+def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None, exact_scores=False):
     """FP8-PV two-level attention with the per-thread Q quantisation done in the kernel prologue
     (``sage_attn_fused_q_pv_f8``): bit-identical to ``per_thread_int8`` + the attention op, one launch and
     3 B/element of HBM traffic less."""
@@ -110,18 +110,19 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
-    ws = ops.attn_launch_ws(q.device, is_causal, B * Hq * ((Lq + 127) // 128))      # (a large non-causal call: persistent launch)
+    # (a large non-causal call: persistent launch; FP8 PV: the score form)
+    attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128), exact_scores and v_scale is not None)
     if v_scale is None:            # FP16 PV (v_image from prep_v_fp16), straight FP32 accumulation
         rc = _cabi.load().sage_attn_fused_q_pv_f16(
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
             B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-            int(is_causal), float(sm_scale_log2), code, code, _stream(q))
+            int(is_causal), float(sm_scale_log2), code, code, _stream(q), _cabi.attr_arg(attr))
         _cabi.check(rc, "sage_attn_fused_q_pv_f16")
         return o, lse
     rc = _cabi.load().sage_attn_fused_q_pv_f8(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_scale), _p(v_mean),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-        int(is_causal), float(sm_scale_log2), code, code, _stream(q))
+        int(is_causal), float(sm_scale_log2), code, code, _stream(q), _cabi.attr_arg(attr))
     _cabi.check(rc, "sage_attn_fused_q_pv_f8")
     return o, lse
 
@@ -138,24 +139,33 @@ def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
-    ws = ops.attn_launch_ws(q.device, is_causal, B * Hq * ((Lq + 127) // 128))
+    attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128))
     rc = _cabi.load().sage_attn_fused_qblock_pv_f16(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-        int(is_causal), float(q_premul), code, code, _stream(q))
+        int(is_causal), float(q_premul), code, code, _stream(q), _cabi.attr_arg(attr))
     _cabi.check(rc, "sage_attn_fused_qblock_pv_f16")
     return o, lse
 
 
-def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override: Optional[int]) -> int:
+def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override, auto_default: bool = True) -> int:
     """Number of key-range chunks S for a call whose grid would not fill the chip (0 = no split).  The reference kernels
     parallelise over (batch, head, 128-row q block) only, so few query rows against a long key range (cross-attention,
     decode-like shapes) leave most of the 256 CUs idle.  Such a call runs as
     S chunks of Lk/S keys folded into the kv-head dimension and one merge by log-sum-exp.  Chunks are whole numbers of
-    64-key tiles (the quantisation groups and the V image tiles are unchanged by the fold), so only S | Lk/64 is considered."""
+    64-key tiles (the quantisation groups and the V image tiles are unchanged by the fold), so only S | Lk/64 is considered.
+    ``override``: 0 = never, an integer S >= 2 = that split, "auto" = the plan below, None = ``auto_default``.  The FP16-PV entry point
+    plans by default (a split result meets the UNSPLIT oracle at the kernel tolerance: P is rounded to fp16).  The FP8-PV entry points do
+    NOT (round 5): a split changes which running maximum every P is rounded to e4m3 against -- measured rel-RMS up to 2.8e-2 against the
+    unsplit oracle, beyond the 1e-2 that a schedule variant may differ from the exact schedule by and still be a DEFAULT FP8 route
+     -- so there it is opt-in (``split_kv="auto"`` or S), held to 2e-3 against the schedule-matched oracle as before."""
+    if override is None:
+        override = "auto" if auto_default else 0
     if override == 0:
         return 0
-    if override:
+    if override != "auto":
+        if isinstance(override, bool) or not isinstance(override, int):
+            raise ValueError(f"split_kv={override!r}: 0, an integer >= 2 or 'auto'")
         if Lk % 64 != 0 or override < 2 or (Lk // 64) % override != 0:
             raise ValueError(f"split_kv={override} must be >= 2 and divide the number of whole 64-key tiles (kv_len {Lk})")
         return override
@@ -177,7 +187,8 @@ def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override:
 
 
 @torch.compiler.disable
-def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, S, return_lse, v_mean=None):
+def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, S, return_lse, v_mean=None,
+                        exact_scores=False):
     """Split-KV route of the fused-Q FP8 attention: the key range in S chunks folded into the kv-head dimension (zero-copy
     views of the INT8 K, its scales and the V image; Q is read in place by every chunk), partial outputs in fp16 +
     log2-domain log-sum-exps, one ``sage_merge_split`` pass."""
@@ -200,13 +211,14 @@ def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_
         rc = lib.sage_attn_fused_q_pv_f16_split(
             _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vm_f),
             B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
-            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
+            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q), None)
         _cabi.check(rc, "sage_attn_fused_q_pv_f16_split")
     else:
         rc = lib.sage_attn_fused_q_pv_f8_split(
             _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
             B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
-            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q))
+            int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q),
+            _cabi.attr_arg(_cabi.launch_attr(exact_scores=bool(exact_scores))))
         _cabi.check(rc, "sage_attn_fused_q_pv_f8_split")
     o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
@@ -237,7 +249,7 @@ def _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, out_dtype
     rc = _cabi.load().sage_attn_qk_int8_pv_f16_masked(
         _p(q_int8), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(q_scale), _p(k_scale), _p(attn_mask), kind,
         attn_mask.stride(0), attn_mask.stride(1), attn_mask.stride(2), attn_mask.stride(3),
-        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, 1.0, code, _stream(o))
+        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, 1.0, code, _stream(o), None)
     _cabi.check(rc, "sage_attn_qk_int8_pv_f16_masked")
     return o, lse
 
@@ -264,7 +276,7 @@ def sageattn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tensor_layout: s
     if arch.startswith(_SUPPORTED_ARCH_PREFIX):
         return sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout=tensor_layout, is_causal=is_causal, sm_scale=sm_scale,
                                             return_lse=return_lse, pv_accum_dtype="fp32+fp32", split_kv=kwargs.get("split_kv"),
-                                            fused_prepass=kwargs.get("fused_prepass"))
+                                            fused_prepass=kwargs.get("fused_prepass"), fp8_scores=kwargs.get("fp8_scores"))
     raise ValueError(f"Unsupported architecture: {arch} (sageattention_amd targets gfx950 / MI355X only)")
 
 
@@ -390,18 +402,19 @@ def _varlen_attend(st: _VarlenState) -> torch.Tensor:
     items, hdr, bound = (plan.items, plan.hdr, plan.items_bound) if plan is not None else (None, None, 0)
     nseq = st.cu_q.shape[0] - 1
     # (a large non-causal call runs as a persistent launch; items = 128-row blocks of the packed rows, at least)
-    ws = ops.attn_launch_ws(q.device, st.is_causal, Hq * (q.shape[0] // 128)) if plan is not None else None
+    attr = ops.attn_attr(q.device, st.is_causal, Hq * (q.shape[0] // 128)) if plan is not None else None
     if st.fuse_q:
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_ks), _p(st.order),
             _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1), st.k_int8.stride(0), st.k_int8.stride(1),
-            o.stride(0), o.stride(1), int(st.is_causal), st.q_premul, code, code, _stream(o))
+            o.stride(0), o.stride(1), int(st.is_causal), st.q_premul, code, code, _stream(o), _cabi.attr_arg(attr))
         _cabi.check(rc, "sage_attn_fused_qblock_pv_f16_varlen")
     else:
         rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.q_scale), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_qs), _p(st.cu_ks),
             _p(st.order), _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1),
-            st.k_int8.stride(0), st.k_int8.stride(1), o.stride(0), o.stride(1), int(st.is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o))
+            st.k_int8.stride(0), st.k_int8.stride(1), o.stride(0), o.stride(1), int(st.is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o),
+            _cabi.attr_arg(attr))
         _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
     return o[..., :st.head_dim_og]
 
@@ -420,7 +433,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
                                           kwargs))
 
 
-_ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant")
+_ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant", "fp8_scores")
 
 
 def _compiled_call(api, q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse,
@@ -586,6 +599,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         smooth_v = False
     fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
     fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")) and k.shape == v.shape
+    exact = ops.fp8_exact(kwargs.get("fp8_scores"))
     if fuse_q:
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM).
         # (Running the V pre-pass on a side stream beside the K chain was measured and rejected: the two HBM-bound chains
@@ -593,19 +607,19 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         lse_correction, _, k_int8, k_scale, v_image, v_scale, vm = _prepass_kv(q, k, v, tensor_layout, "per_thread", 64, smooth_k, smooth_v,
                                                                                return_lse, fused)
         B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
-        n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
+        n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"), auto_default=False)
         if n_split:
             o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal,
-                                         _sm_log2(sm_scale), n_split, return_lse, v_mean=vm)
+                                         _sm_log2(sm_scale), n_split, return_lse, v_mean=vm, exact_scores=exact)
         else:
             o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
-                                   return_lse, v_mean=vm)
+                                   return_lse, v_mean=vm, exact_scores=exact)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     lse_correction, _, k_int8, k_scale, v_image, v_scale, vm = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, smooth_v,
                                                                            return_lse, fused)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 32, sm_scale)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm)
+                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm, exact_scores=exact)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
@@ -635,5 +649,5 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_ca
                                                                           return_lse, fused)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 16, sm_scale, blkk=128)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, True, return_lse)
+                         gran, q_warp, sm_log2, True, return_lse, exact_scores=ops.fp8_exact(kwargs.get("fp8_scores")))
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)

@@ -1,1730 +1,16 @@
-// sage_attn.hip -- fused INT8-QK^T / online-softmax / FP8-or-FP16-PV attention for gfx950.
-//
-// Replaces (behaviourally, not textually) the reference kernels
-//   csrc/qattn/qk_int_sv_f8_cuda_sm89.cuh:46-704   (INT8 QK, FP8 PV, two-level accumulation)
-//   csrc/qattn/qk_int_sv_f8_cuda_sm90.cu:127-567   (same, 128-key tiles, RO += RO_temp per tile)
-//   csrc/qattn/qk_int_sv_f16_cuda_sm80.cu:46-671   (INT8 QK, FP16 PV)
-//   sageattention/triton/attn_qk_int8_per_block*.py, attn_qk_int8_block_varlen.py (+causal)
-// with one CDNA4 kernel family.  Design:
-//
-//  * workgroup = 4 waves = 128 query rows of one (batch, q-head); wave w owns rows 32w..32w+31.
-//  * swapped product S^T = K Q^T on v_mfma_i32_32x32x32_i8: A = K tile rows from LDS, B = Q
-//    fragments kept in VGPRs for the whole kernel.  In the 32x32 C layout a lane then holds 16
-//    keys of ONE query row (col = lane&31), so row max / row sum are in-lane chains plus one
-//    v_permlane32_swap with the lane^32 partner.
-//  * P is converted in registers (v_cvt_pk_fp8_f32 / cvt f16) and is already the B operand of
-//    O^T = V^T P^T: the V pre-pass stores V^T tiles in the matching "position" order
-//    (sage_common.h), so P never goes through LDS.  FP8 PV runs on the block-scaled
-//    v_mfma_scale_f32_32x32x64_f8f6f4 with unit E8M0 scales: identical products and FP32
-//    accumulation, twice the rate of the non-scaled 32x32x16 fp8 MFMA.
-//  * one loop iteration covers NH 64-key images (NH = 2 -> 128 keys, the sm90 reference's tile):
-//    one row max, one rescale and one two-level fold per iteration; scales and masks stay per
-//    64-key block.  Two-level accumulation: the iteration's P.V product starts from a zero
-//    accumulator and is folded into the FP32 running output with one FMA (O = O*alpha + T).
-//  * K/V tiles are double-buffered in LDS and arrive by LDS-DMA (global_load_lds_dwordx4); the
-//    K image is XOR-swizzled through the per-lane SOURCE address, the V image is pre-swizzled
-//    by the pre-pass: every MFMA operand read is a conflict-free ds_read_b128.
-//  * output tile is transposed through (now free) LDS and stored as whole rows, 16 B per lane.
+// sage_attn.hip -- host-side dispatch of the attention launches: the work order of a launch (sage_work_order.h) and the choice of the
+// instantiation unit (sage_attn_parts.h; the kernels themselves are in sage_attn_kernel.h, compiled by sage_attn_d*_*.hip).
 #include "sage_common.h"
 #include "sage_kernels.h"
-#include "sage_quant_math.h"
+#include "sage_attn_parts.h"
 #include "sage_work_order.h"
-#include <climits>
 #include <cstdlib>
-#include <type_traits>
 
-// ---- build-time switches used for the A/B ladder in DESIGN.md ------------------------------------
-#ifndef SAGE_GLDS       // K/V tiles by LDS-DMA instead of VGPR staging (+4%)
-#define SAGE_GLDS 1
-#endif
-#ifndef SAGE_MXPV       // FP8 PV on the block-scaled K=64 MFMA with unit scales (+5%)
-#define SAGE_MXPV 1
-#endif
-#ifndef SAGE_KPRELOAD   // steady iteration: request all K fragments before the first QK MFMA
-#define SAGE_KPRELOAD 1
-#endif
-#ifndef SAGE_STEADY     // branch-free steady-state iteration for whole, unmasked tiles
-#define SAGE_STEADY 1
-#endif
-#ifndef SAGE_STAGES     // LDS ring depth: 3 = two tiles in flight, counted vmcnt + raw s_barrier (needs SAGE_GLDS)
-#define SAGE_STAGES 3
-#endif
-#ifndef SAGE_NH_F8      // 64-key images per iteration (2 = 128-key tiles: spills at D=128 today)
-#define SAGE_NH_F8 1
-#endif
-
-#ifndef SAGE_MAGIC      // the int32 QK^T accumulators start from the bit pattern of the inline constant 1/(2 pi) = 0x3E22F983 (free as
-#define SAGE_MAGIC 1    // the MFMA's C operand): read as a float they are 1/(2 pi) + s * 2^-26 exactly, so one exact v_sub_f32 (2 cycles)
-#endif                  // replaces v_cvt_f32_i32 (4) and the 2^26 goes into the scale: bit-identical scores (see sfl below)
-#ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
-#define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
-#endif
-#ifndef SAGE_PIPE16     // the software-pipelined steady-state loop for FP16 PV as well
-#define SAGE_PIPE16 1
-#endif
-#ifndef SAGE_PLAIN_PV   // pipelined FP8 loop: v_mfma_f32_32x32x64_f8f6f4 instead of its block-scaled form with unit scales
-#define SAGE_PLAIN_PV 1
-#endif
-#ifndef SAGE_GRP4       // experiment: the FP8 pipelined loop's softmax in statements of four scores
-#define SAGE_GRP4 1
-#endif
-#ifndef SAGE_RSUM_MFMA   // experiment: FP16-PV CUDA form, pipelined loop: the row sum of the fp16-rounded P from the matrix pipe (a ones
-#define SAGE_RSUM_MFMA 0 // fragment against P, the reference's mma::rowsum_f16f16f32) instead of two v_fma_mix_f32 per score pair
-#endif
-#ifndef SAGE_ATTN_TRACE      // experiment (tools/attn_trace.py): wave 0 of every workgroup records 100 MHz time stamps of its phases
-#define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
-#endif
 #ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
 #define SAGE_ORDER_DEFAULT -1
 #endif
-#ifndef SAGE_FOLDBIAS   // pipelined loops: the bias of the score's bit pattern (SAGE_MAGIC) is removed inside the scale FMA,
-#define SAGE_FOLDBIAS 1 // exp2(fma(bits, c, -(m + bias * c))), instead of by a v_add_f32 of its own per score (32 VALU instructions of ~195
-#endif                  // per wave-tile).  m + bias * c is rounded once per (row, tile, k scale): an error of up to 0.64 of ONE integer step
-                        // of the INT8 x INT8 score in the exponent (2^-24 * 0.159 * 2^26 * dequantisation scale ~ 1e-4 on randn inputs), against
-                        // a quantisation noise of ~ 10^2 steps.  1: FP16 PV only -- there P is rounded to fp16 and the perturbation stays far
-                        // below the parity bar (every oracle test green).  With FP8 PV the same perturbation moves P across e4m3 rounding
-                        // boundaries (one step = 6-12 % of that P) a few times per row: statistically the same result, +2.5 % at C3 and
-                        // +6.7 % at C5 (profiles/r4_run_b_foldbias_ab.txt), but up to 1.3e-2 * max|o| away from the oracle on 300-500 key
-                        // rows where the bar is 2e-3 -- so the FP8 loops keep the exact subtraction.  2: fold everywhere (experiment);
-                        // 0 = the separate, exact subtraction everywhere (bit-identical to rounds 2-3)
-#ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
-#define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
-#endif
-
-#ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow.  The software-pipelined FP8 loop carries two
-                        // score tiles at D=128 (248 VGPRs: 2 waves; measured equal to 3 waves for the phased loop); D=64 fits 3 (167).
-                        // Phased loops: 3 (<= 168 VGPRs, +3.5% measured) wherever that does not spill.
-#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) \
-    ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : ((PV_FP8) ? (((SAGE_PIPE != 0) && (SAGE_MAGIC != 0) && (!(TWO_LEVEL) || (SAGE_DIRECT != 0))) ? 2 : (((TWO_LEVEL) || !(KTHREAD)) ? 3 : 2)) : 2)))
-#endif
-
-// asm text of the pipelined loops: two scores d0 / d1 from the bit patterns s0 / s1 of the QK^T accumulators, d = score * c - m (operands as
-// asm placeholders).  FOLD: one FMA per score, m already carries the bias of the bit pattern (SAGE_FOLDBIAS); EXACT: the bias is
-// subtracted first (exact), then the FMA
-#define SAGE_SCALE2_FOLD(d0, d1, s0, s1, c0, c1, m) "v_fma_f32 " d0 ", " s0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " s1 ", " c1 ", -" m "\n\t"
-#define SAGE_SCALE2_EXACT(d0, d1, s0, s1, c0, c1, m) "v_add_f32 " d0 ", 0xbe22f983, " s0 "\n\tv_add_f32 " d1 ", 0xbe22f983, " s1 "\n\t" \
-                                                      "v_fma_f32 " d0 ", " d0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " d1 ", " c1 ", -" m "\n\t"
 
 namespace sage {
-
-template <int D, bool PV_FP8, int NH> struct TileCfg {
-    static constexpr int KT = BLKK * NH;                        // keys per iteration
-    static constexpr int K_TILE_BYTES = KT * D;                 // int8
-    static constexpr int V_ROW_BYTES = PV_FP8 ? 64 : 128;       // one 64-key image row
-    static constexpr int V_IMG_BYTES = D * V_ROW_BYTES;
-    static constexpr int STAGE_BYTES = K_TILE_BYTES + NH * V_IMG_BYTES;
-    static constexpr int O_BYTES = BLKQ * D * 2;
-    static constexpr int NSTAGE = (SAGE_GLDS && SAGE_STAGES == 3) ? 3 : 2;
-    static constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > O_BYTES) ? NSTAGE * STAGE_BYTES : O_BYTES;
-    static constexpr int KSTEPS = D / 32;                       // i8 MFMA k-steps over head dim
-    static constexpr int DT = D / 32;                           // 32-wide output d tiles
-};
-
-// c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
-__device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
-
-// raw QK^T accumulator -> float score (in units of kSUnit^-1).
-// 0x3E22F983 lies mid-binade ([0.125, 0.25), ulp 2^-26, mantissa field 2292099): for |s| <= 128 * 128 * 128 = 2097152 the sum
-// stays inside the binade, so bits + s is the float 1/(2 pi) + s * 2^-26, the subtraction below is exact (Sterbenz) and
-// fma(s * 2^-26, c * 2^26, -m) rounds the same real number as fma((float)s, c, -m): bit-identical to the conversion.
-[[maybe_unused]] constexpr int kSInit = SAGE_MAGIC ? 0x3E22F983 : 0;
-constexpr float kSUnit = SAGE_MAGIC ? 67108864.0f : 1.0f;       // 2^26: folded into the score scale
-__device__ __forceinline__ float sfl(int x)
-{
-#if SAGE_MAGIC
-    return __int_as_float(x) - __int_as_float(0x3E22F983);
-#else
-    return (float)x;
-#endif
-}
-// first MFMA of a QK^T accumulation chain: C = kSInit as an inline constant (hipcc materialises an integer splat of
-// 0x3E22F983 in 16 VGPRs instead; the assembler encodes it as inline operand 248).  The builtin MFMAs that follow take the
-// result whole as their C operand (accumulate chain: no wait states, cdna_hip_programming.md 5.7 item 2).
-__device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
-{
-#if SAGE_MAGIC
-    v16i d;
-    asm("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(d) : "v"(a), "v"(b));
-    return d;
-#else
-    const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, z, 0, 0, 0);
-#endif
-}
-
-#if SAGE_ATTN_TRACE
-constexpr int kAttnTraceWgs = 1 << 15;
-__device__ unsigned g_attn_trace[16 * kAttnTraceWgs];      // 16 words per workgroup: 8 stamps, -, HW_ID, XCC_ID
-#define SAGE_TSTAMP(i) do { if (wave == 0) { unsigned long long t_; \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ttrace[i] = (unsigned)t_; } } while (0)
-#else
-#define SAGE_TSTAMP(i) do { } while (0)
-#endif
-
-// QF: 0 = q is INT8 with scales in q_scale; 1 / 2 = q is fp16 / bf16 and is quantised in the prologue, per-thread groups;
-// 3 / 4 = fp16 / bf16 quantised in the prologue PER BLOCK of 128 rows after the multiplication by p.q_premul (quant_per_block.py:21-46
-// with sm_scale folded in: the Q half of the reference's Triton-named API and of sageattn_varlen),
-// ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0>
-__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
-sage_attn_kernel(const AttnParams p_arg)
-{
-    // The parameter block is read through the kernarg segment pointer, and inside the persistent loop through a copy of that pointer the
-    // compiler cannot see through (an empty asm): otherwise every scalar load of a parameter is hoisted out of the loop and stays live in
-    // SGPRs across it (128 SGPRs and 16-400 VGPRs spilled in every instantiation).  AttnParams is the kernel's only explicit argument.
-    typedef const __attribute__((address_space(4))) AttnParams *kparams_t;
-    const kparams_t kp0 = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
-    const __attribute__((address_space(4))) AttnParams &p = *kp0;
-    (void)p_arg;
-    using C = TileCfg<D, PV_FP8, NH>;
-    constexpr int KT = C::KT;
-    constexpr int NS = 2 * NH;                       // 32-key S^T sub-tiles per iteration
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    // (wave index in an SGPR, lane index from v_mbcnt wherever it is needed: nothing derived from threadIdx.x has to stay in a VGPR across
-    //  the persistent loop below)
-    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#if SAGE_ATTN_TRACE
-    __shared__ unsigned ttrace[16];
-#endif
-    // ---- persistent launch (p.sched != null; non-causal, unmasked instantiations only): gridDim.x workgroups -- as many as the device holds at
-    //      once -- work through the logical grid of p.nwg workgroup indices.  The indices are dealt into 32 queues: index i belongs to XCD i & 7
-    //      (the work order's L2 locality, sage_work_order.h) and there to sub-queue (i >> 3) & 3, i.e. i = 32 k + 8 s + x.  A workgroup starts with
-    //      its own blockIdx.x (the hardware deals blockIdx.x to XCD blockIdx.x & 7) and then takes tickets k from the counter of its queue -- the
-    //      ticket is requested behind the last tile of the item in hand and read after its output rows are on their way.  When that queue is empty
-    //      it looks at all 32 counters once and takes a ticket from the fullest queue, its own XCD's first (the XCDs of a device run a few per cent
-    //      apart: profiles/r4_run_p_attention_phase_trace.txt).  One counter per 128-byte line, zeroed by the caller: agent-scope atomics on one
-    //      address serialise at ~200 ns each, and the 64 workgroups of an XCD finish equal items together.
-    //      Causal launches keep the hardware's dispatch: their work order pairs a long and a short block on a CU through the order in which
-    //      freed slots are refilled, and tickets lose that (measured: +2.6 % at C3, +7 % at C2).
-    constexpr bool PERS_OK = !CAUSAL && MASK == 0;
-    const bool pers = PERS_OK && p.sched != nullptr;
-    __shared__ int s_ticket[2];                 // (two slots, alternating: a wave may still be reading the previous ticket when wave 0 posts the next)
-    int tpar = 0;
-    int bid = blockIdx.x;
-    int nwg_l = 0;                               // the logical grid
-    const int sched_first = gridDim.x >> 5;      // tickets of every queue that the first round (blockIdx.x) covers
-    const int my_xcd = pers ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;      // HW_REG_XCC_ID[3:0]
-    const int my_q = 4 * my_xcd + (int)((blockIdx.x >> 3) & 3u);
-    unsigned next_k_v = 0;                       // (lane 0 of wave 0) the ticket requested ahead
-    bool have_next = false, own_empty = false;   // wave-uniform
-    // wave 0: the next logical workgroup index, or -1 when every queue is empty
-    auto resolve_ticket = [&]() -> int {
-        if (have_next) {
-            have_next = false;
-            const int i = 32 * ((int)__builtin_amdgcn_readfirstlane(next_k_v) + sched_first) + 8 * (my_q & 3) + my_xcd;
-            if (i < nwg_l) return i;
-            own_empty = true;
-        }
-        int lane_o = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_o));         // (or the per-lane queue addresses below are computed once, outside the item loop, and stay live)
-        for (int attempt = 0; attempt < 4; attempt++) {
-            // lane q < 32 looks at queue q; the fullest queue wins, queues of the own XCD before the others
-            const int q = lane_o & 31, x = q >> 2, s8x = 8 * (q & 3) + x;
-            const unsigned c = lane_o < 32 ? __hip_atomic_load(p.sched + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            const int cnt = nwg_l > s8x ? (nwg_l - s8x + 31) >> 5 : 0;
-            int left = cnt - sched_first - (int)c;
-            left = left < (1 << 24) ? left : (1 << 24) - 1;
-            unsigned key = (lane_o < 32 && left > 0) ? ((x == my_xcd ? 1u : 0u) << 30) | ((unsigned)left << 5) | (unsigned)q : 0u;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { const unsigned o = __shfl_xor(key, m); key = o > key ? o : key; }
-            key = __builtin_amdgcn_readfirstlane(key);
-            if (key == 0u) return -1;
-            const int bq = (int)(key & 31u);
-            unsigned kv = 0;
-            if (lane_o == 0) kv = __hip_atomic_fetch_add(p.sched + 32 * bq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int i = 32 * ((int)__builtin_amdgcn_readfirstlane(kv) + sched_first) + 8 * (bq & 3) + (bq >> 2);
-            if (i < nwg_l) return i;
-        }
-        return -1;
-    };
-    if (pers) {
-        nwg_l = p.nwg;
-        if (p.cu_q != nullptr && p.work_items != nullptr) {
-            typedef const __attribute__((address_space(4))) int *cint_p;
-            const cint_p hdr = (cint_p)p.work_hdr;
-            nwg_l = 8 * (hdr[3] * ((hdr[0] + 7) >> 3) + (p.Hq >> 3) * hdr[0]);
-        }
-    }
-    while (bid >= 0) {
-    next_k_v = 0;                                // (defined at the top of every pass: not carried round the loop in a VGPR)
-    do {
-    kparams_t kp = kp0;
-    if constexpr (PERS_OK) asm volatile("" : "+s"(kp));
-    const __attribute__((address_space(4))) AttnParams &p = *kp;
-    // (the same for everything derived from the thread index: hoisted out of the loop, the prologue's and the epilogue's per-lane
-    //  offsets would stay live through the key loop -- 13-32 VGPRs spilled in every instantiation)
-    int lane_v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if constexpr (PERS_OK) asm volatile("" : "+v"(lane_v));
-    const int lane = lane_v;
-    const int wave = wave_s;
-    const int tid = wave * 64 + lane;
-    const int n = lane & 31;      // query row inside the wave's 32-row tile
-    const int g = lane >> 5;      // k-group (operand half)
-    SAGE_TSTAMP(0);
-
-    // ---- work item: XCD-aware, heavy-first --------------------------------------------------
-    const int nqblk = p.nqblk;
-    int b, h, hk, qblk;
-    if (p.cu_q != nullptr && p.work_items != nullptr) {
-        // varlen with the device-built work list (sage_varlen_plan): the query blocks of all sequences are one item list per query head,
-        // heaviest first, and the launch is a dense launch over Hq heads of `nitems` items each (sage_work_order.h) -- whole GQA groups
-        // stay on one XCD, every workgroup has an item (the grid is sized by a host-known bound of nitems; the few past it exit here)
-        typedef const __attribute__((address_space(4))) int *cint_p;          // wave-uniform: scalar loads
-        const cint_p hdr = (cint_p)p.work_hdr;
-        const int nitems = hdr[0];
-        const WorkOrder wo = {hdr[1], hdr[2], hdr[3]};
-        const int nwg = 8 * (wo.left * ((nitems + 7) >> 3) + (p.Hq >> 3) * nitems);
-        int qrank;
-        if (bid >= nwg || !work_item(wo, bid, nwg, p.Hq, nitems, h, qrank)) break;
-        const cint_p items = (cint_p)p.work_items;
-        b = items[2 * qrank];
-        qblk = items[2 * qrank + 1];
-        hk = h / p.group;
-    } else if (p.cu_q != nullptr) {
-        // varlen without a work list (more sequences than sage_varlen_plan takes): sequences differ in length, so a contiguous run
-        // per XCD would hand one XCD the longest sequence
-        // (measured 3.5x slower on lengths 256..16384).  XCDs take (sequence, kv-head) units round-robin instead;
-        // inside a unit the `group` query heads that share the K/V stream run heavy-first, interleaved.
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int per_unit = nqblk * p.group;
-        const int j = idx / per_unit, within = idx - j * per_unit;
-        const int u = j * 8 + xcd;
-        if (u >= p.B * p.Hkv) break;
-        const int r = within / p.group, hg = within - r * p.group;
-        qblk = nqblk - 1 - r;
-        const int bs = u / p.Hkv;
-        hk = u - bs * p.Hkv;
-        b = p.seq_order != nullptr ? p.seq_order[bs] : bs;      // caller's processing order (longest first)
-        h = hk * p.group + hg;
-    } else {
-        // workgroups bid, bid+8, bid+16.. share an XCD (bid % 8); each XCD takes one contiguous run of work items,
-        // so the q-blocks of one head -- and the query heads of one GQA group -- stream K/V through one L2, and the
-        // longest (causal) blocks of a head are dispatched first.  Measured alternatives (profiles/r1_run28_xcd_map.txt,
-        // DESIGN.md 3.1): heads dealt to XCDs in rounds of 8 is 6-14 % slower where it spreads a head's K/V over all
-        // eight L2s; shortest-first order -5 %, alternating long/short -21 %.
-        int bh, qrank;
-        const WorkOrder wo = {CAUSAL ? p.order_group : 0, p.order_fold, p.order_left};      // causal work order: sage_work_order.h
-        if (!work_item(wo, bid, pers ? p.nwg : (int)gridDim.x, p.B * p.Hq, nqblk, bh, qrank)) break;
-        qblk = nqblk - 1 - qrank;
-        b = bh / p.Hq;
-        h = bh - b * p.Hq;
-        hk = h / p.group;
-    }
-
-    // ---- per-sequence geometry ---------------------------------------------------------------
-    int Lq = p.Lq, Lk = p.Lk;
-    long q_off, k_off, o_off;
-    long v_tile0, v_tstride;              // V image index = v_tile0 + t * v_tstride
-    const float *qs_ptr, *ks_ptr;
-    int qs_stride, ks_tstride;
-    if (p.cu_q != nullptr) {              // varlen: packed [sum L, H, D]
-        // the prefix arrays are read-only here and the sequence index is wave-uniform: scalar loads, requested together (as vector loads they
-        // were a memory round trip of their own behind the work list's; measured neutral at C4, profiles/r4_run_p_attention_phase_trace.txt)
-        typedef const __attribute__((address_space(4))) int *cint_p;
-        const int bu = __builtin_amdgcn_readfirstlane(b);
-        const int q0 = ((cint_p)p.cu_q)[bu], k0 = ((cint_p)p.cu_k)[bu], q1 = ((cint_p)p.cu_q)[bu + 1], k1 = ((cint_p)p.cu_k)[bu + 1];
-        const int ks0 = ((cint_p)p.cu_ks)[bu];
-        Lq = q1 - q0;
-        Lk = k1 - k0;
-        if (qblk * BLKQ >= Lq) break;
-        q_off = (long)q0 * p.q_sl + (long)h * p.q_sh;
-        k_off = (long)k0 * p.k_sl + (long)hk * p.k_sh;
-        o_off = (long)q0 * p.o_sl + (long)h * p.o_sh;
-        v_tile0 = (long)ks0 * p.Hkv + hk;
-        v_tstride = p.Hkv;
-        qs_ptr = QF == 0 ? p.q_scale + ((long)((cint_p)p.cu_qs)[bu] + qblk) * p.Hq + h : nullptr;    // [sum nblk, Hq] (fused Q: no stored scales)
-        qs_stride = 0;
-        ks_ptr = p.k_scale + (long)ks0 * p.Hkv + hk;                  // [sum nblk, Hkv]
-        ks_tstride = p.Hkv;
-    } else {
-        // split-KV (p.kv_split = S > 1): the key range is folded into the kv-head dimension, kv head hk = hk0 * S + chunk and query
-        // head h = hk * group + g; the query rows are those of head hk0 * group + g (read in place, no per-chunk copy of Q)
-        const int hq = p.kv_split > 1 ? (hk / p.kv_split) * p.group + (h - hk * p.group) : h;
-        q_off = (long)b * p.q_sb + (long)hq * p.q_sh;
-        k_off = (long)b * p.k_sb + (long)hk * p.k_sh;
-        o_off = (long)b * p.o_sb + (long)h * p.o_sh;
-        const int ntk = (Lk + BLKK - 1) / BLKK;
-        v_tile0 = ((long)b * p.Hkv + hk) * ntk;
-        v_tstride = 1;
-        qs_ptr = p.q_scale + ((long)b * p.Hq + h) * p.nqs + (long)qblk * p.qs_per_blk;
-        qs_stride = 1;
-        ks_ptr = p.k_scale + ((long)b * p.Hkv + hk) * p.nks;
-        ks_tstride = KTHREAD ? 4 : 1;
-    }
-
-    SAGE_TSTAMP(1);
-    const int row0 = qblk * BLKQ + wave * 32;        // first query row of this wave
-    const int my_row = row0 + n;
-    // causal mask in the chunk's key coordinates (split-KV: this workgroup sees keys kchunk0 .. kchunk0 + Lk - 1 as 0 .. Lk - 1):
-    // key <= row  <=>  local key <= row - kchunk0
-    const int kchunk0 = (CAUSAL && p.kv_split > 1 && p.cu_q == nullptr) ? (hk % p.kv_split) * Lk : 0;
-    const int crow0 = row0 - kchunk0, cmy_row = my_row - kchunk0;
-    const int ntk_all = (Lk + BLKK - 1) / BLKK;      // 64-key images that exist
-    int n_iters = (Lk + KT - 1) / KT;
-    if (CAUSAL) {
-        int lim = (qblk * BLKQ + BLKQ - kchunk0 + KT - 1) / KT;      // <= 0: the whole chunk lies behind the diagonal
-        lim = lim > 0 ? lim : 0;
-        n_iters = lim < n_iters ? lim : n_iters;
-    }
-
-    // ---- Q fragments (B operand of S^T = K Q^T), resident in VGPRs ---------------------------
-    v4i qf[C::KSTEPS];
-    float qsc;
-    // ---- tile staging ------------------------------------------------------------------------
-    const unsigned char *kbase = reinterpret_cast<const unsigned char *>(p.k) + k_off;
-    const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v);
-    constexpr int CPR = D / 16;                                   // 16-B chunks per K row
-#if SAGE_GLDS
-    // LDS-DMA: every wave-instruction moves 64 x 16 B = 1 KiB; the LDS destination is lane-linear
-    // (M0 base + lane*16), so the XOR swizzle of the K image goes on the per-lane SOURCE address.
-    // Key rows past Lk are clamped to the last valid row, V images past the last one to the last
-    // image (their probabilities are exactly zero: masked scores).
-    constexpr int KP = C::K_TILE_BYTES / 1024, VP = C::V_IMG_BYTES / 1024;   // 1-KiB pieces
-    // per-lane source offsets are loop-invariant: tile base pointers advance in SGPRs, so a full
-    // tile costs no VALU address arithmetic per iteration
-    unsigned koff[KP / 4];
-#pragma unroll
-    for (int i = 0; i < KP / 4; i++) {
-        const int e = (wave * (KP / 4) + i) * 64 + lane;       // 16-B slot index inside the tile
-        const int row = e / CPR, phys = e % CPR;
-        koff[i] = (unsigned)(row * (int)p.k_sl + swz_chunk<D>(row, phys) * 16);
-    }
-    auto issue_loads = [&](auto steady_tag, int it, int buf) {      // steady: tile `it` is known to be a whole tile
-        unsigned char *ks = smem + buf * C::STAGE_BYTES;
-        unsigned char *vs = ks + C::K_TILE_BYTES;
-        const unsigned char *kt = kbase + (long)it * KT * p.k_sl;
-        if (decltype(steady_tag)::value || it * KT + KT <= Lk) {
-#pragma unroll
-            for (int i = 0; i < KP / 4; i++) {
-                const int pc = wave * (KP / 4) + i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kt + koff[i]),
-                                                 (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < KP / 4; i++) {
-                const int pc = wave * (KP / 4) + i;
-                const int e = pc * 64 + lane;
-                const int row = e / CPR, phys = e % CPR;
-                int key = it * KT + row;
-                key = key < Lk ? key : Lk - 1;
-                const unsigned char *src = kbase + (long)key * p.k_sl + swz_chunk<D>(row, phys) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(ks + pc * 1024), 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            int tv = it * NH + hh;
-            if (!decltype(steady_tag)::value) tv = tv < ntk_all ? tv : ntk_all - 1;
-            const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
-#pragma unroll
-            for (int i = 0; i < VP / 4; i++) {
-                const int pc = wave * (VP / 4) + i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(vs + hh * C::V_IMG_BYTES + pc * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto write_lds = [&](int) {};
-#else
-    constexpr int K_LD = C::K_TILE_BYTES / 4096, V_LD = C::V_IMG_BYTES / 4096;
-    v4u kreg[K_LD], vreg[NH][V_LD];
-    auto issue_loads = [&](auto, int it, int) {
-#pragma unroll
-        for (int i = 0; i < K_LD; i++) {
-            const int piece = tid * K_LD + i;
-            const int row = piece / CPR, ch = piece % CPR;
-            int key = it * KT + row;
-            key = key < Lk ? key : Lk - 1;
-            kreg[i] = *reinterpret_cast<const v4u *>(kbase + (long)key * p.k_sl + ch * 16);
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            int tv = it * NH + hh;
-            tv = tv < ntk_all ? tv : ntk_all - 1;
-            const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
-#pragma unroll
-            for (int i = 0; i < V_LD; i++) vreg[hh][i] = *reinterpret_cast<const v4u *>(vt + (i * 256 + tid) * 16);
-        }
-    };
-    auto write_lds = [&](int buf) {
-        unsigned char *ks = smem + buf * C::STAGE_BYTES;
-        unsigned char *vs = ks + C::K_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < K_LD; i++) {
-            const int piece = tid * K_LD + i;
-            const int row = piece / CPR, ch = piece % CPR;
-            *reinterpret_cast<v4u *>(ks + row * D + swz_chunk<D>(row, ch) * 16) = kreg[i];
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++)
-#pragma unroll
-            for (int i = 0; i < V_LD; i++)
-                *reinterpret_cast<v4u *>(vs + hh * C::V_IMG_BYTES + (i * 256 + tid) * 16) = vreg[hh][i];
-    };
-#endif
-
-    // ---- running state -------------------------------------------------------------------------
-    v16f o[C::DT];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; dt++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) o[dt][i] = 0.0f;
-    float m_run = kNegBig, l_run = 0.0f;
-    constexpr float OFF = PV_FP8 ? kFp8Offset : 0.0f;
-
-    // K scales of an iteration are fetched one iteration ahead with SCALAR loads (constant address
-    // space, wave-uniform index -> s_load, tracked by lgkmcnt).  An ordinary VMEM load here would be
-    // fatal for the pipeline: with LDS-DMA in flight hipcc waits vmcnt(0) at the first use of any
-    // VGPR-destination load, draining the in-flight tiles every iteration.
-    typedef const __attribute__((address_space(4))) float *cfloat_p;
-    const cfloat_p ks_c = (cfloat_p)(ks_ptr);
-    float ksc[NH][2];
-    auto load_kscales = [&](int it, float (&dst)[NH][2]) {
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            int tk = it * NH + hh;
-            tk = tk < ntk_all ? tk : ntk_all - 1;
-            const long tb = (long)(tk >> p.ks_shift) * ks_tstride;
-            if (KTHREAD) {      // 4 key scales per 64 keys: token%8/2 (quant_per_thread.py:75-83); lane half g uses 2g, 2g+1
-                const float s0 = ks_c[tb], s1 = ks_c[tb + 1], s2 = ks_c[tb + 2], s3 = ks_c[tb + 3];
-                dst[hh][0] = g ? s2 : s0;
-                dst[hh][1] = g ? s3 : s1;
-            } else {
-                dst[hh][0] = dst[hh][1] = ks_c[tb];
-            }
-        }
-    };
-    // LDS ring.  NSTAGE == 3: tiles it+1 and it+2 are in flight while tile it is consumed; a wave waits
-    // only for ITS OWN older DMA group with a counted s_waitcnt vmcnt(N) (N = DMA instructions of the
-    // younger group) and then meets the others at a raw s_barrier -- __syncthreads() would drain
-    // vmcnt(0) and expose the full L2/HBM latency every iteration (cdna_hip_programming.md T3+T4).
-    constexpr int NSTAGE = C::NSTAGE;
-#if SAGE_GLDS
-    constexpr int DMA_PER_TILE = KP / 4 + NH * (VP / 4);          // per wave
-#else
-    constexpr int DMA_PER_TILE = 0;
-#endif
-    auto ring_wait = [&](bool younger_in_flight) {
-        if constexpr (NSTAGE == 3) {
-            if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            __syncthreads();
-        }
-    };
-    if (n_iters > 0) {
-        load_kscales(0, ksc);
-        issue_loads(std::false_type{}, 0, 0);
-        write_lds(0);
-    }
-    if (NSTAGE == 3 && n_iters > 1) issue_loads(std::false_type{}, 1, 1);
-    // The Q fragments are fetched AFTER the first tiles' LDS-DMA has been issued: hipcc waits vmcnt(0) at the first use of an
-    // ordinary VGPR load, and with the Q loads in front it did so after the first DMA instruction -- the Q round trip and the
-    // tiles' round trip ran one after the other in every workgroup's prologue.
-    if constexpr (QF == 0) {
-        const int8_t *qrow = reinterpret_cast<const int8_t *>(p.q) + q_off + (long)my_row * p.q_sl;
-        const bool ok = my_row < Lq;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            v4i z = {0, 0, 0, 0};
-            qf[ks] = ok ? *reinterpret_cast<const v4i *>(qrow + 32 * ks + 16 * g) : z;
-        }
-        // this lane's query-row scale (per-block / per-warp / per-thread granularity)
-        int slot;
-        const int rin = wave * 32 + n;               // row inside the 128-row block
-        if (p.q_gran == QG_PER_BLOCK) slot = 0;
-        else if (p.q_gran == QG_PER_WARP32) slot = rin >> 5;
-        else if (p.q_gran == QG_PER_WARP16) slot = rin >> 4;
-        else if (p.q_gran == QG_PER_THREAD16) slot = (rin >> 4) * 8 + (rin & 7);   // per-thread, WARPQ = 16 (core.py:604,969)
-        else slot = (rin >> 5) * 8 + (rin & 7);      // per-thread: quant_per_thread.py:27-37
-        qsc = qs_ptr[slot * qs_stride];
-    } else {
-        // Fused Q quantisation.  The lane holds channels [32 ks + 16 g, +16) of its row for every ks -- the layout of
-        // the MFMA B operand -- so it quantises exactly the bytes it needs.  A per-thread group is the rows
-        // r, r+8, r+16, r+24 of the wave's 32-row tile, all 128 channels: lanes n = r (mod 8), both halves g.
-        constexpr int QDT = (QF == 1 || QF == 3) ? DT_F16 : DT_BF16;
-        constexpr bool QBLOCK = QF >= 3;
-        const float premul = QBLOCK ? p.q_premul : 1.0f;
-        const uint16_t *qrow = reinterpret_cast<const uint16_t *>(p.q) + q_off + (long)my_row * p.q_sl;
-        const bool ok = my_row < Lq;
-        float x[C::KSTEPS][16];
-        float amax = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            v4u raw[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-            if (ok) {
-                raw[0] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g);
-                raw[1] = *reinterpret_cast<const v4u *>(qrow + 32 * ks + 16 * g + 8);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const unsigned w = raw[j >> 3][(j & 7) >> 1];
-                float f = ld16<QDT>((uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
-                if constexpr (QBLOCK) f *= premul;          // x.to(float32) * sm_scale before the abs-max (quant_per_block.py:35-37)
-                x[ks][j] = f;
-                amax = fmaxf(amax, fabsf(f));
-            }
-        }
-        if constexpr (QBLOCK) {
-            // one scale for the workgroup's 128 rows: the wave's maximum, then the four waves' through 16 bytes of LDS (the K / V ring
-            // is receiving its first tiles meanwhile; only this word is waited for)
-            amax = fmaxf(amax, __shfl_xor(amax, 1));
-            amax = fmaxf(amax, __shfl_xor(amax, 2));
-            amax = fmaxf(amax, __shfl_xor(amax, 4));
-        }
-        amax = fmaxf(amax, __shfl_xor(amax, 8));
-        amax = fmaxf(amax, __shfl_xor(amax, 16));
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
-        if constexpr (QBLOCK) {
-            __shared__ float q_amax[4];
-            if (lane == 0) q_amax[wave] = amax;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            amax = fmaxf(fmaxf(q_amax[0], q_amax[1]), fmaxf(q_amax[2], q_amax[3]));
-        }
-        const float sc = quant_scale(amax, QBLOCK ? QS_TRITON : QS_TRITON_THREAD);
-        const float y = quant_recip(sc);
-        qsc = sc;
-#pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ks++) {
-            int q8[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) q8[j] = QBLOCK ? quant_round_triton(x[ks][j], sc, y) : quant_round_triton_nz(x[ks][j], sc, y);
-#pragma unroll
-            for (int w = 0; w < 4; w++) qf[ks][w] = (int)pack_int8x4(q8[4 * w], q8[4 * w + 1], q8[4 * w + 2], q8[4 * w + 3]);
-        }
-    }
-
-    SAGE_TSTAMP(2);
-    ring_wait(NSTAGE == 3 && n_iters > 1);
-    SAGE_TSTAMP(3);
-
-    int cur = 0;
-    // One K/V tile.  STEADY = the tile is whole and unmasked for every wave of the workgroup and tiles it+1, it+2
-    // exist and are whole: all wave-uniform conditionals of the general form fold away (the general iteration
-    // spends 14 scalar branches per tile on them).
-    auto tile_iter = [&](auto steady_tag, const int it) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const bool more = STEADY || (it + 1) < n_iters;
-        const bool more2 = STEADY || (it + 2) < n_iters;
-        const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        float ksc_next[NH][2];
-        if (more) load_kscales(it + 1, ksc_next);
-        if constexpr (NSTAGE == 3) {
-            if (more2) issue_loads(steady_tag, it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
-        } else {
-            if (more) issue_loads(std::false_type{}, it + 1, nxt);
-        }
-
-        // number of 64-key halves with at least one key this wave may attend to (wave-uniform)
-        int nact = STEADY ? NH : 0;
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            const int key0 = it * KT + hh * BLKK;
-            if (!STEADY && key0 < Lk && (!CAUSAL || key0 <= crow0 + 31)) nact = hh + 1;
-        }
-        // ---- attn_mask (Triton-named API only; attn_qk_int8_per_block.py:31-51): additive term per
-        //      score in the log2 domain.  bool: 0 / -1e6, and a tile whose whole 128x64 mask block is
-        //      False is skipped; float: the mask value itself; out-of-range positions count as False / -1e6.
-        float mk[MASK ? NS : 1][16];
-        bool skip_tile = false;
-        if constexpr (MASK != 0) {
-            const unsigned char *mbase = reinterpret_cast<const unsigned char *>(p.mask);
-            const long mrow = (long)b * p.m_sb + (long)h * p.m_sh + (long)my_row * p.m_sq;
-            int anytrue = 0;
-#pragma unroll
-            for (int sb = 0; sb < NS; sb++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int key = it * KT + sb * 32 + crow(i, g);
-                    const bool inb = (my_row < Lq) && (key < Lk);
-                    float add = -1.0e6f;
-                    if (inb) {
-                        const long idx = mrow + (long)key * p.m_sk;
-                        if (MASK == 1) { const bool t = mbase[idx] != 0; add = t ? 0.0f : -1.0e6f; anytrue |= (int)t; }
-                        else if (MASK == 2) add = f16_to_f32(reinterpret_cast<const uint16_t *>(mbase)[idx]);
-                        else add = bf16_to_f32(reinterpret_cast<const uint16_t *>(mbase)[idx]);
-                    }
-                    mk[sb][i] = add;
-                }
-            if (MASK == 1) skip_tile = !__syncthreads_or(anytrue);
-        }
-        if (STEADY || (nact > 0 && !skip_tile)) {
-            const unsigned char *ks = smem + cur * C::STAGE_BYTES;
-            const unsigned char *vs = ks + C::K_TILE_BYTES;
-            const int last_key = it * KT + nact * BLKK - 1;
-            const bool full = STEADY || ((MASK == 0) && (nact == NH) && !(CAUSAL && last_key > crow0) && (last_key < Lk));
-
-            // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
-            v16i s[NS];
-#if SAGE_KPRELOAD
-            if constexpr (STEADY) {
-                // All K fragments of the tile are requested before the first MFMA and the two 32-key chains are
-                // interleaved.  Left alone, hipcc keeps ONE fragment buffer to save registers and emits
-                // ds_read -> wait -> MFMA six times per tile, exposing the LDS latency every time.
-                v4i kf[NS][C::KSTEPS];
-#pragma unroll
-                for (int sb = 0; sb < NS; sb++) {
-                    const int krow = sb * 32 + n;
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-                        kf[sb][kk] = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < C::KSTEPS; kk++)
-#pragma unroll
-                    for (int sb = 0; sb < NS; sb++) {
-                        s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
-                    }
-            } else
-#endif
-#pragma unroll
-            for (int sb = 0; sb < NS; sb++) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) s[sb][i] = 0;        // sub-tiles past the wave's last key are masked below
-                if (STEADY || sb < 2 * nact) {
-                    const int krow = sb * 32 + n;
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        const v4i a = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                        s[sb] = kk == 0 ? mfma_i8_first(a, qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[kk], s[sb], 0, 0, 0);
-                    }
-                }
-            }
-
-            // ---- scales: c multiplies the raw int32 score into the log2 domain, formed in the reference's order
-            //      sm_scale*log2e * (q_scale * k_scale)  (qk_int_sv_f8_cuda_sm89.cuh:263-266,334-335) ----
-            float cs[NH][2];
-#pragma unroll
-            for (int hh = 0; hh < NH; hh++) {
-                cs[hh][0] = (p.sm_scale_log2 * (qsc * ksc[hh][0])) * kSUnit;
-                cs[hh][1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[hh][1])) * kSUnit : cs[hh][0];
-            }
-
-            // ---- online softmax over the iteration's keys ----
-            // The row max is taken on the raw int32 scores (c >= 0, so max commutes with the scale);
-            // only the per-(half, scale) maxima are converted.  exp2 / row sum / low-precision pack
-            // are fused per 8-register chunk so no float copy of S stays live.
-            float m_new;
-            if (full) {
-                float mxc = -INFINITY;
-#pragma unroll
-                for (int hh = 0; hh < NH; hh++) {
-                    int mx0 = INT_MIN, mx1 = INT_MIN;
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            if (KTHREAD && (i & 2)) mx1 = max(mx1, s[2 * hh + u][i]);
-                            else mx0 = max(mx0, s[2 * hh + u][i]);
-                        }
-                    // m_temp = fma(max raw score, scale, -offset)  (attn_utils.cuh:372-384)
-                    mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx0), cs[hh][0], -OFF));
-                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[hh][1], -OFF));
-                }
-                m_new = fmaxf(m_run, pair_max(mxc));
-            } else {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int sb = 0; sb < NS; sb++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        if (sb < 2 * nact) {
-                            const float cc = cs[sb >> 1][(KTHREAD && (i & 2)) ? 1 : 0];
-                            const int key = it * KT + sb * 32 + crow(i, g);
-                            const bool ok = (key < Lk) && (!CAUSAL || key <= cmy_row);
-                            if constexpr (MASK != 0) mx = fmaxf(mx, (ok ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i] - OFF);
-                            else mx = fmaxf(mx, ok ? __builtin_fmaf(sfl(s[sb][i]), cc, -OFF) : -INFINITY);
-                        }
-                    }
-                m_new = fmaxf(m_run, pair_max(mx));
-            }
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            if (!TWO_LEVEL) {
-#pragma unroll
-                for (int dt = 0; dt < C::DT; dt++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
-            }
-
-            // P for chunk c (16 keys) of half hh = registers 8u..8u+7 of S^T tile 2hh + (c>>1):
-            // exactly the order of the PV B operand (sage_common.h)
-            // Row sum.  The reference's FP16-PV CUDA kernels sum the fp16-ROUNDED probabilities (RS_32_to_16, then the tensor-core
-            // row sum mma::rowsum_f16f16f32: qk_int_sv_f16_cuda_sm80.cu:313-320, attn_utils.cuh:529-545, DenominatorAccumUnit =
-            // kTensorCore in every instantiation); its Triton kernels and FP8 kernels sum the un-rounded ones
-            // (attn_qk_int8_per_block.py:57-60, qk_int_sv_f8_cuda_sm90.cu:317-318).  For FP16 PV the C ABI maps the two forms onto
-            // the TWO_LEVEL parameter: false = the CUDA kernels' form (SAGE_PV_ACCUM_SINGLE / _TWO_LEVEL: gfx950 accumulates P.V
-            // in FP32 whatever tile buffer the reference would use), true = the Triton kernels' form
-            // (SAGE_PV_ACCUM_TRITON: tile product folded into the FP32 output, un-rounded denominator).
-            constexpr bool sum_rounded = !PV_FP8 && !TWO_LEVEL;
-            float rs = 0.0f;
-            auto p_chunk = [&](auto masked, auto rnd, int hh, int c, float (&e)[8]) {
-                const int sb = 2 * hh + (c >> 1), r0 = (c & 1) * 8;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int i = r0 + j;
-                    const float cc = cs[hh][(KTHREAD && (i & 2)) ? 1 : 0];
-                    float v;
-                    if constexpr (MASK != 0) {
-                        const int key = it * KT + sb * 32 + crow(i, g);
-                        v = __builtin_amdgcn_exp2f(((key < Lk) ? sfl(s[sb][i]) * cc : 0.0f) + mk[sb][i] - m_new);
-                    } else {
-                        v = __builtin_amdgcn_exp2f(__builtin_fmaf(sfl(s[sb][i]), cc, -m_new));
-                        if constexpr (decltype(masked)::value) {
-                            const int key = it * KT + sb * 32 + crow(i, g);
-                            const bool ok = (sb < 2 * nact) && (key < Lk) && (!CAUSAL || key <= cmy_row);
-                            v = ok ? v : 0.0f;
-                        }
-                    }
-                    e[j] = v;
-                    if constexpr (decltype(rnd)::value) rs += (float)(_Float16)v;
-                    else rs += v;
-                }
-            };
-
-            if constexpr (PV_FP8) {
-                int pw[NH][8];                   // 32 fp8 per 64-key half = B operand of one K=64 MFMA
-                auto build_p = [&](auto masked) {
-#pragma unroll
-                    for (int hh = 0; hh < NH; hh++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            float e[8];
-                            p_chunk(masked, std::false_type{}, hh, c, e);
-                            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], __float_as_int(e[0]), false);   // high half is overwritten next
-                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
-                            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], __float_as_int(e[4]), false);
-                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
-                            pw[hh][2 * c] = w0;
-                            pw[hh][2 * c + 1] = w1;
-                        }
-                };
-                if (full) build_p(std::false_type{});
-                else build_p(std::true_type{});
-                l_run = l_run * alpha + rs;      // lane-partial; the pair is summed in the epilogue
-                auto pv = [&](auto fold_tag) {
-                    constexpr bool FOLD = decltype(fold_tag)::value;     // tile product from zero, then O = O * alpha + T
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
-                        v16f acc;
-                        if (FOLD) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-                        } else acc = o[dt];
-#pragma unroll
-                        for (int hh = 0; hh < NH; hh++) {
-                            if (STEADY || hh < nact) {
-                                const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
-                                const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                                const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-#if SAGE_MXPV
-                                // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0)
-                                const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
-                                const v8i bv = {pw[hh][0], pw[hh][1], pw[hh][2], pw[hh][3], pw[hh][4], pw[hh][5], pw[hh][6], pw[hh][7]};
-                                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-#else
-#define SAGE_L(lo, hi) ((long)(((unsigned long)(unsigned)(hi) << 32) | (unsigned long)(unsigned)(lo)))
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[0], va[1]), SAGE_L(pw[hh][0], pw[hh][1]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[2], va[3]), SAGE_L(pw[hh][2], pw[hh][3]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[0], vb[1]), SAGE_L(pw[hh][4], pw[hh][5]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[2], vb[3]), SAGE_L(pw[hh][6], pw[hh][7]), acc, 0, 0, 0);
-#undef SAGE_L
-#endif
-                            }
-                        }
-                        if (FOLD) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
-                        } else o[dt] = acc;
-                    }
-                };
-                if constexpr (!TWO_LEVEL) pv(std::false_type{});
-                else pv(std::true_type{});
-            } else {
-                v8h pb[NH][4];
-                auto build_p = [&](auto masked, auto rnd) {
-#pragma unroll
-                    for (int hh = 0; hh < NH; hh++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            float e[8];
-                            p_chunk(masked, rnd, hh, c, e);
-#pragma unroll
-                            for (int j = 0; j < 8; j++) pb[hh][c][j] = (_Float16)e[j];
-                        }
-                };
-                if (full) build_p(std::false_type{}, std::integral_constant<bool, sum_rounded>{});
-                else build_p(std::true_type{}, std::integral_constant<bool, sum_rounded>{});
-                l_run = l_run * alpha + rs;
-                auto pv = [&](auto fold_tag) {
-                    constexpr bool FOLD = decltype(fold_tag)::value;
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
-                        v16f acc;
-                        if (FOLD) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-                        } else acc = o[dt];
-#pragma unroll
-                        for (int hh = 0; hh < NH; hh++) {
-                            if (STEADY || hh < nact) {
-                                const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
-#pragma unroll
-                                for (int c = 0; c < 4; c++) {
-                                    const v8h a = *reinterpret_cast<const v8h *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[hh][c], acc, 0, 0, 0);
-                                }
-                            }
-                        }
-                        if (FOLD) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++) o[dt][i] = __builtin_fmaf(o[dt][i], alpha, acc[i]);
-                        } else o[dt] = acc;
-                    }
-                };
-                if constexpr (!TWO_LEVEL) pv(std::false_type{});
-                else pv(std::true_type{});
-            }
-        }
-
-        if (more) {
-            write_lds(nxt);
-#pragma unroll
-            for (int hh = 0; hh < NH; hh++) { ksc[hh][0] = ksc_next[hh][0]; ksc[hh][1] = ksc_next[hh][1]; }
-        }
-        ring_wait(more2);
-        cur = nxt;
-    };
-
-    int it = 0;
-#if SAGE_STEADY
-    if constexpr (MASK == 0 && NH == 1 && NSTAGE == 3) {
-        // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
-        int n_steady = Lk / KT - 2;
-        n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
-        if (CAUSAL) {                                  // unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk - kchunk0
-            int nd = (qblk * BLKQ - kchunk0) / KT;
-            nd = nd > 0 ? nd : 0;
-            n_steady = n_steady < nd ? n_steady : nd;
-        }
-
-#if SAGE_PIPE
-        if constexpr (PV_FP8 && SAGE_MXPV && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
-            // ---- software-pipelined steady state -------------------------------------------------------------
-            // Iteration t runs softmax(t) on the VALU and deals, between its instruction groups, the PV MFMAs of tile t-1
-            // (P and V fragments carried in registers) and the QK^T MFMAs of tile t+1 (K fragments read at the top), so a
-            // wave's matrix work is covered by its OWN VALU stream instead of depending on another wave being in the right
-            // phase.  The instruction ORDER is the design here, and hipcc re-orders builtin arithmetic freely (it clustered
-            // the MFMAs and sank the softmax below them), so every instruction of the main stream is a one-line
-            // `asm volatile`: hipcc still allocates the registers, counts its own ds_read / s_load / LDS-DMA and waits for
-            // them, but cannot move the statements.  Hazards it therefore does not pad (cdna_hip_programming.md 5.7):
-            //   * v_exp_f32 -> first VALU reader: one other instruction in between (groups of two scores are interleaved);
-            //   * freshly loaded / written VGPR -> MFMA A/B operand: every MFMA statement opens with s_nop 1;
-            //   * MFMA result -> VALU reader: PV results are read at the next iteration's top or after the drain's s_nops,
-            //     QK^T results after the 18-instruction tail + barrier; an MFMA taking the previous result whole as C needs none.
-            // O is rescaled (rarely) at the top of the next iteration, i.e. after PV(t-1) and before PV(t): the single-level
-            // order O = O*alpha + P V, which the FP32 MFMA accumulator makes equivalent to the two-level fold.
-            // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
-            // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
-#define SAGE_FOLD8 (SAGE_FOLDBIAS >= 2)
-#if SAGE_FOLD8
-#define SAGE_SCALE2 SAGE_SCALE2_FOLD
-#else
-#define SAGE_SCALE2 SAGE_SCALE2_EXACT
-#endif
-#define A_FMAN(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#define A_EXP(d, a)        asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a))
-#define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
-#define A_PKLO(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
-#define A_PKHI(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(a), "v"(b))
-#define SAGE_NOPX "s_nop 1\n\t"
-#if SAGE_PLAIN_PV    // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix (same products; 8 bytes and one VGPR less per MFMA)
-#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#else
-#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
-#endif
-#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile(SAGE_NOPX "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-#define A_FENCE()          asm volatile("" ::: "memory")
-            if (it < n_steady) {
-                v16i sA[2], sB[2];
-                {
-                    const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
-                    v4i kf0[2][C::KSTEPS];
-#pragma unroll
-                    for (int sb = 0; sb < 2; sb++) {
-                        const int krow = sb * 32 + n;
-#pragma unroll
-                        for (int kk = 0; kk < C::KSTEPS; kk++)
-                            kf0[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-#pragma unroll
-                        for (int sb = 0; sb < 2; sb++)
-                            sA[sb] = kk == 0 ? mfma_i8_first(kf0[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf0[sb][kk], qf[kk], sA[sb], 0, 0, 0);
-                }
-                v8i pA = {0, 0, 0, 0, 0, 0, 0, 0}, pB = {0, 0, 0, 0, 0, 0, 0, 0};   // P of the previous tile (none yet: zero, the first PV adds nothing)
-                v8i vf[C::DT];                                                        // V fragments of the previous tile
-#pragma unroll
-                for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
-                [[maybe_unused]] const int e8m0 = 0x7f7f7f7f;     // unit block scales (SAGE_PLAIN_PV == 0)
-                static_assert(KP / 4 == VP / 4 && (KP / 4 == 1 || KP / 4 == 2), "asm LDS-DMA: one or two pieces per wave and image");
-                const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-                const unsigned voff16 = lane * 16;
-                const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;    // piece 1's source offset minus its inst_offset
-                const float sm26 = p.sm_scale_log2 * kSUnit;
-                float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
-                auto rescale = [&]() {
-                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
-#pragma unroll
-                        for (int dt = 0; dt < C::DT; dt++)
-#pragma unroll
-                            for (int i = 0; i < 16; i++) o[dt][i] *= alpha_p;
-                    }
-                };
-                // one tile: sc = scores of tile `it` (complete), sn <- scores of tile it+1, pp = P of tile it-1, pc <- P of tile it
-                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {
-                    rescale();
-                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-                    const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
-                    const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    {
-                        // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
-                        // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
-                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
-                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 2) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
-                        const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
-                        const unsigned ldv = lds_base + nn * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
-                        unsigned keep;
-                        if constexpr (KP / 4 == 2)
-                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
-                                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %7, %4\n\tglobal_load_lds_dwordx4 %7, %4 offset:1024\n\t"
-                                         "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
-                        else
-                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %1, %2\n\t"
-                                         "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %6, %3\n\t"
-                                         "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
-                    }
-                    float cs[2];                 // (sm * (q_scale * k_scale)) * 2^26 == (sm * 2^26) * (q_scale * k_scale): exact power-of-two scaling
-                    cs[0] = sm26 * (qsc * ksc[0][0]);
-                    cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
-
-                    // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
-                    // (nothing is in flight on lgkmcnt here, so hipcc's own wait for the V fragments in front of this MFMA is free;
-                    //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
-                    A_PV(o[0], vf[0], pp, e8m0);
-                    A_FENCE();
-                    float ksc_next[NH][2];
-                    load_kscales(it + 1, ksc_next);
-                    v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
-                    }
-                    A_FENCE();
-                    int mx0 = INT_MIN, mx1 = INT_MIN;
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
-                            else mx0 = max(mx0, sc[u][i]);
-                        }
-                    float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
-                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
-                    const float m_new = fmaxf(m_run, pair_max(mxc));
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-#if SAGE_FOLD8
-                    // what the scale FMA subtracts: the row maximum plus the bias of the score's bit pattern in this tile's scale
-                    const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
-                    const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
-#else
-                    const float mb0 = m_new, mb1 = m_new;
-#endif
-                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
-                    A_FENCE();
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
-                    }
-                    A_FENCE();
-
-                    // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
-                    float rs0 = 0.0f, rs1 = 0.0f;
-                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
-                        const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
-                        const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
-                        float t0, t1;
-                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
-#define SAGE_GRP(PACK)                                                                                                          \
-                        asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")                                        \
-                                     "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
-                                     "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t" PACK                                      \
-                                     : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "+v"(pc[h >> 1])                               \
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"((KTHREAD && (i0 & 2)) ? mb1 : mb0))
-                        if ((h & 1) == 0) SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3");
-                        else SAGE_GRP("v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
-#undef SAGE_GRP
-                    };
-                    auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
-                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
-                    };
-                    auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vs + drow * 64;
-                        const v4u a = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
-                        const v4u b = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-                        vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-                    };
-#if SAGE_GRP4
-                    // experiment: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
-                    // can sit between the exponentials and the adds
-                    float u0, u1, u2, u3;
-                    auto g4a = [&](int w) {
-                        const int sb = w >> 2, i0 = 4 * (w & 3);
-#if SAGE_FOLD8
-                        asm volatile(SAGE_SCALE2_FOLD("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2_FOLD("%2", "%3", "%6", "%7", "%9", "%9", "%11")
-#else
-                        asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
-                                     "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
-                                     "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
-                                     "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11\n\t"
-#endif
-                                     "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"
-                                     : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
-                    };
-                    auto g4b = [&](int w) {
-                        asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
-                                     "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
-                                     : "+v"(rs0), "+v"(rs1), "+v"(pc[w])
-                                     : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
-                    };
-                    if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp, e8m0);
-                        g4a(0); g4b(0);
-                        A_PV(o[3], vf[3], pp, e8m0);
-                        g4a(1); g4b(1);
-                        qk_next(0, 0); g4a(2);
-                        qk_next(0, 1); g4b(2); g4a(3);
-                        qk_next(0, 2); g4b(3);
-                        qk_next(0, 3); g4a(4);
-                        A_FENCE(); read_v(0); read_v(1); A_FENCE();
-                        g4b(4);
-                        qk_next(1, 0); g4a(5);
-                        qk_next(1, 1); g4b(5); g4a(6);
-                        qk_next(1, 2); g4b(6);
-                        qk_next(1, 3);
-                        A_FENCE(); read_v(2); read_v(3); A_FENCE();
-                        g4a(7); g4b(7);
-                    } else
-#endif
-                    if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp, e8m0);
-                        grp(0); grp(1);
-                        A_PV(o[3], vf[3], pp, e8m0);
-                        grp(2); grp(3);
-                        qk_next(0, 0); grp(4);
-                        qk_next(0, 1); grp(5); grp(6);
-                        qk_next(0, 2); grp(7);
-                        qk_next(0, 3); grp(8);
-                        A_FENCE(); read_v(0); read_v(1); A_FENCE();
-                        grp(9);
-                        qk_next(1, 0); grp(10);
-                        qk_next(1, 1); grp(11); grp(12);
-                        qk_next(1, 2); grp(13);
-                        qk_next(1, 3);
-                        A_FENCE(); read_v(2); read_v(3); A_FENCE();
-                        grp(14); grp(15);
-                    } else {                         // D = 64: two PV MFMAs (dealt above), four QK^T MFMAs
-                        grp(0); grp(1); grp(2); grp(3);
-                        qk_next(0, 0); grp(4); grp(5); grp(6);
-                        qk_next(0, 1); grp(7); grp(8); grp(9);
-                        A_FENCE(); read_v(0); A_FENCE();
-                        qk_next(1, 0); grp(10); grp(11); grp(12);
-                        qk_next(1, 1);
-                        A_FENCE(); read_v(1); A_FENCE();
-                        grp(13); grp(14); grp(15);
-                    }
-                    l_run = l_run * alpha + (rs0 + rs1);
-                    ksc[0][0] = ksc_next[0][0];
-                    ksc[0][1] = ksc_next[0][1];
-                    cur = nxt;
-                    alpha_p = alpha;
-                    it++;
-                };
-                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
-                    body(sA, sB, pA, pB);
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-                    sA[0] = sB[0]; sA[1] = sB[1]; pA = pB;
-                }
-#pragma nounroll
-                while (it < n_steady) {
-                    body(sA, sB, pA, pB);
-                    body(sB, sA, pB, pA);
-                }
-                // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
-                // iteration issues the LDS-DMA of tile it+2 into that slot
-                rescale();
-#pragma unroll
-                for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA, e8m0);
-                asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-#undef SAGE_SCALE2
-#undef SAGE_FOLD8
-#undef A_FMAN
-#undef A_EXP
-#undef A_ACC
-#undef A_PKLO
-#undef A_PKHI
-#undef A_PV
-#undef A_QK0
-#undef A_QK
-#undef A_FENCE
-        } else
-#endif
-#if SAGE_PIPE && SAGE_PIPE16
-        if constexpr (!PV_FP8 && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
-            // ---- software-pipelined steady state, FP16 PV --------------------------------------------------------------------
-            // Same structure as the FP8 loop above; differences:
-            //  * PV(t-1) is 4 x DT v_mfma_f32_32x32x16_f16 whose V fragments do not fit in registers next to two score tiles,
-            //    so they are read from LDS as they are needed, one 32-channel tile (4 x ds_read_b128) ahead of its MFMAs;
-            //  * V(t-1) must therefore stay in LDS through iteration t.  The 3-slot ring still suffices because a slot's K and
-            //    V regions are filled separately: at the top of iteration t the LDS-DMA brings K(t+2) into the K region of
-            //    slot (t+2)%3 (K(t-1), read in iteration t-2, is dead) and V(t+1) into the V region of slot (t+1)%3 (V(t-2),
-            //    read in iteration t-1, is dead); K(t+1) and V(t-1) were requested one and two iterations ago.
-#if SAGE_FOLDBIAS
-#define SAGE_SCALE2 SAGE_SCALE2_FOLD
-#else
-#define SAGE_SCALE2 SAGE_SCALE2_EXACT
-#endif
-#define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#define A_RS0(acc, av, bv)  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
-#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-#define A_FENCE()          asm volatile("" ::: "memory")
-            if (it < n_steady) {
-                v16i sA[2], sB[2];
-                {
-                    const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
-                    v4i kf0[2][C::KSTEPS];
-#pragma unroll
-                    for (int sb = 0; sb < 2; sb++) {
-                        const int krow = sb * 32 + n;
-#pragma unroll
-                        for (int kk = 0; kk < C::KSTEPS; kk++)
-                            kf0[sb][kk] = *reinterpret_cast<const v4i *>(ks0 + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-#pragma unroll
-                        for (int sb = 0; sb < 2; sb++)
-                            sA[sb] = kk == 0 ? mfma_i8_first(kf0[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf0[sb][kk], qf[kk], sA[sb], 0, 0, 0);
-                }
-                v4i pA[4], pB[4];                  // P of a tile as fp16 pairs: [chunk of 16 keys][word] = B operands of the PV MFMAs
-#pragma unroll
-                for (int c = 0; c < 4; c++) { pA[c] = v4i{0, 0, 0, 0}; pB[c] = v4i{0, 0, 0, 0}; }
-                const float sm26 = p.sm_scale_log2 * kSUnit;
-                static_assert(KP / 4 == 1 || KP / 4 == 2, "asm LDS-DMA: one or two K pieces per wave");
-                static_assert(VP / 4 == 2 * (KP / 4), "fp16 V image = two K tiles");
-                const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-                const unsigned voff16 = lane * 16;
-                const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
-                float alpha_p = 1.0f;
-                auto rescale = [&]() {
-                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
-#pragma unroll
-                        for (int dt = 0; dt < C::DT; dt++)
-#pragma unroll
-                            for (int i = 0; i < 16; i++) o[dt][i] *= alpha_p;
-                    }
-                };
-                bool first = true;                 // no previous tile yet: P = 0 against the (finite) V of the current slot
-                // CUDA kernel form (TWO_LEVEL false): row sum of the fp16-rounded P; Triton kernel form (TWO_LEVEL true): of the
-                // un-rounded P (see tile_iter)
-                constexpr bool RSUM16 = !TWO_LEVEL;
-                constexpr bool RSMFMA = RSUM16 && SAGE_RSUM_MFMA && D == 128;       // (D = 64: spills at three waves)
-                // RSMFMA: rsacc = ones(32 x 16) . P(t-1)^T chunk by chunk beside the PV MFMAs: every register of the lane holds the
-                // whole row sum of its query row (both lane halves); it joins l one tile late, l(t-1) = l + rs(t-1), then * alpha(t)
-                [[maybe_unused]] v16f rsacc;
-                [[maybe_unused]] v4i ones16 = {0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};
-                if constexpr (RSMFMA) {
-                    asm volatile("" : "+v"(ones16));
-#pragma unroll
-                    for (int i = 0; i < 16; i++) rsacc[i] = 0.0f;
-                }
-                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
-                    rescale();
-                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-                    const int prv = first ? cur : nn;                 // slot of tile t-1 = (cur + 2) % 3
-                    first = false;
-                    const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
-                    const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    {   // LDS-DMA: K(t+2) -> K region of slot nn, V(t+1) -> V region of slot nxt (SGPR-base form, see the FP8 loop)
-                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
-                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
-                        const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
-                        const unsigned ldv = lds_base + nxt * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
-                        unsigned keep;
-                        if constexpr (KP / 4 == 2)
-                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
-                                         "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %7, %4\n\tglobal_load_lds_dwordx4 %7, %4 offset:1024\n\t"
-                                         "global_load_lds_dwordx4 %7, %4 offset:2048\n\tglobal_load_lds_dwordx4 %7, %4 offset:3072\n\t"
-                                         "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
-                        else
-                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %1, %2\n\t"
-                                         "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                                         "global_load_lds_dwordx4 %6, %3\n\tglobal_load_lds_dwordx4 %6, %3 offset:1024\n\t"
-                                         "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
-                    }
-                    float cs[2];
-                    cs[0] = sm26 * (qsc * ksc[0][0]);
-                    cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
-                    // V fragments of tile t-1, one 32-channel tile at a time (two register sets, alternating)
-                    v4i vfa[4], vfb[4];
-                    auto read_v = [&](int dt, v4i (&vf)[4]) {
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vsp + drow * 128;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) vf[c] = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
-                    };
-                    read_v(0, vfa);
-                    A_FENCE();
-                    // ---- row maximum of S(t) (plain code) ----
-                    int mx0 = INT_MIN, mx1 = INT_MIN;
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
-                            else mx0 = max(mx0, sc[u][i]);
-                        }
-                    float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
-                    if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
-                    const float m_new = fmaxf(m_run, pair_max(mxc));
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-#if SAGE_FOLDBIAS
-                    const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
-                    const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
-#else
-                    const float mb0 = m_new, mb1 = m_new;
-#endif
-                    A_FENCE();
-                    if constexpr (C::DT > 1) read_v(1, vfb);
-                    A_FENCE();
-
-                    float rs0 = 0.0f, rs1 = 0.0f;
-                    auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32: bias sub, scale fma, exp2, fp16 pack, row sum
-                        const int c = h >> 2, j0 = (h & 3) * 2;
-                        const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
-                        float t0, t1;
-                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
-                        const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
-                        if constexpr (RSMFMA) {
-                            asm volatile(SAGE_SCALE2("%0", "%1", "%3", "%4", "%5", "%6", "%7")
-                                         "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\t"
-                                         "s_nop 0\n\tv_cvt_pk_f16_f32 %2, %0, %1"
-                                         : "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
-                        } else if constexpr (RSUM16) {
-                            // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
-                            // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
-                            // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
-                            // outputs 0.6-1.7 % too large on Lk = 333 with per-block scales).  The reference takes this sum from the
-                            // tensor core (see tile_iter).
-                            asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")
-                                         "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
-                                         "s_nop 0\n\tv_cvt_pk_f16_f32 %4, %2, %3\n\t"
-                                         "v_fma_mix_f32 %0, %4, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-                                         "v_fma_mix_f32 %1, %4, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                                         : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
-                        } else {
-                            asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")
-                                         "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
-                                         "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t"
-                                         "v_cvt_pk_f16_f32 %4, %2, %3"
-                                         : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "=v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
-                        }
-                    };
-                    v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
-                    auto read_k = [&](int sb, v4i (&kf)[C::KSTEPS]) {
-                        const int krow = sb * 32 + n;
-#pragma unroll
-                        for (int kk = 0; kk < C::KSTEPS; kk++)
-                            kf[kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                    };
-                    auto pv4 = [&](int dt, v4i (&vf)[4], int c) {
-                        A_PV16(o[dt], vf[c], pp[c]);
-                        if constexpr (RSMFMA) {                                  // the row-sum MFMA of chunk c rides behind channel tile 1 (D=64: 0)
-                            if (dt == (C::DT == 4 ? 1 : 0)) { if (c == 0) A_RS0(rsacc, ones16, pp[0]); else A_PV16(rsacc, ones16, pp[c]); }
-                        }
-                    };
-                    auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
-                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
-                    };
-                    if constexpr (C::DT == 4) {
-                        // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
-                        // Two 32-channel tiles are in flight and their MFMAs alternate, so consecutive MFMAs never share an
-                        // accumulator (a dependent MFMA issued behind other instructions waits for the full write-back).
-                        pv4(0, vfa, 0); grp(0);
-                        pv4(1, vfb, 0); grp(1);
-                        pv4(0, vfa, 1); pv4(1, vfb, 1); grp(2);
-                        pv4(0, vfa, 2); grp(3);
-                        pv4(1, vfb, 2); grp(4);
-                        pv4(0, vfa, 3);
-                        A_FENCE(); read_v(2, vfa); A_FENCE();
-                        pv4(1, vfb, 3);
-                        A_FENCE(); read_v(3, vfb); A_FENCE();
-                        grp(5); grp(6);
-                        pv4(2, vfa, 0); grp(7);
-                        pv4(3, vfb, 0); grp(8);
-                        pv4(2, vfa, 1); pv4(3, vfb, 1); grp(9);
-                        pv4(2, vfa, 2); grp(10);
-                        pv4(3, vfb, 2);
-                        pv4(2, vfa, 3);
-                        A_FENCE(); read_k(0, kfa); A_FENCE();
-                        pv4(3, vfb, 3);
-                        A_FENCE(); read_k(1, kfb); A_FENCE();
-                        grp(11); grp(12);
-                        qk_next(0, 0); qk_next(1, 0); grp(13);
-                        qk_next(0, 1); qk_next(1, 1); grp(14);
-                        qk_next(0, 2); qk_next(1, 2); grp(15);
-                        qk_next(0, 3); qk_next(1, 3);
-                    } else {                         // D = 64: 8 PV + 4 QK^T MFMAs
-                        pv4(0, vfa, 0); grp(0);
-                        pv4(0, vfa, 1); grp(1);
-                        pv4(0, vfa, 2); grp(2);
-                        pv4(0, vfa, 3); grp(3);
-                        A_FENCE(); read_k(0, kfa); A_FENCE();
-                        pv4(1, vfb, 0); grp(4);
-                        pv4(1, vfb, 1); grp(5);
-                        pv4(1, vfb, 2); grp(6);
-                        pv4(1, vfb, 3); grp(7);
-                        A_FENCE(); read_k(1, kfb); A_FENCE();
-                        grp(8); grp(9);
-                        qk_next(0, 0); grp(10); grp(11);
-                        qk_next(0, 1); grp(12);
-                        qk_next(1, 0); grp(13); grp(14);
-                        qk_next(1, 1); grp(15);
-                    }
-                    A_FENCE();
-                    float ksc_next[NH][2];
-                    load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
-                    if constexpr (RSMFMA) l_run = (l_run + (g == 0 ? rsacc[0] : 0.0f)) * alpha;     // lane-partial convention: half 0 carries the sum
-                    else l_run = l_run * alpha + (rs0 + rs1);
-                    ksc[0][0] = ksc_next[0][0];
-                    ksc[0][1] = ksc_next[0][1];
-                    cur = nxt;
-                    alpha_p = alpha;
-                    it++;
-                };
-                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
-                    body(sA, sB, pA, pB);
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-                    sA[0] = sB[0]; sA[1] = sB[1];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pA[c] = pB[c];
-                }
-#pragma nounroll
-                while (it < n_steady) {
-                    body(sA, sB, pA, pB);
-                    body(sB, sA, pB, pA);
-                }
-                // drain: PV of the last pipelined tile (its V is in slot (cur + 2) % 3); V(it+1) is requested so that the general
-                // iteration finds tile it+1 "in flight" as a whole; then tile `it` must be complete and every wave past its reads
-                rescale();
-                {
-                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                    const int prv = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-                    const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
-                    unsigned char *vsn = smem + nxt * C::STAGE_BYTES + C::K_TILE_BYTES;
-                    const unsigned char *vt = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES;
-                    // V(it+1) lands in the V region of slot nxt, which held V(it-2): the tile whose fragments the LAST loop
-                    // iteration read (late in its body: channel tiles 2, 3).  Every wave must be past those reads before any
-                    // wave's DMA may overwrite them -- inside the loop the barrier at the top of the body orders this; here
-                    // nothing did, and a fast wave could corrupt a slow wave's last PV (seen as 32 rows x channels 64..127 of
-                    // one head differing between two identical calls, once in a few hundred launches).
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-#pragma unroll
-                    for (int i = 0; i < VP / 4; i++) {
-                        const int pc_ = wave * (VP / 4) + i;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc_ * 1024 + lane * 16),
-                                                         (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
-                    }
-#pragma unroll
-                    for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vsp + drow * 128;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            const v4i a = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
-                            A_PV16(o[dt], a, pA[c]);
-                        }
-                    }
-                    if constexpr (RSMFMA) {
-                        A_RS0(rsacc, ones16, pA[0]);
-#pragma unroll
-                        for (int c = 1; c < 4; c++) A_PV16(rsacc, ones16, pA[c]);
-                    }
-                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VP / 4) : "memory");
-                    if constexpr (RSMFMA) l_run += (g == 0 ? rsacc[0] : 0.0f);
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
-#undef A_RS0
-#undef SAGE_SCALE2
-#undef A_PV16
-#undef A_QK0
-#undef A_QK
-#undef A_FENCE
-        } else
-#endif
-        {
-#pragma nounroll
-            for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
-        }
-    }
-#endif
-#pragma nounroll
-    for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
-    SAGE_TSTAMP(4);
-    __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
-    SAGE_TSTAMP(5);
-    // persistent launch: the next ticket is requested here, behind the last tile, and read after the output rows are on their way
-    if (pers && !own_empty) {
-        if (tid == 0) next_k_v = __hip_atomic_fetch_add(p.sched + 32 * my_q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        have_next = true;
-    }
-
-    // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
-    const float l_tot = pair_sum(l_run);
-    const float inv = l_tot > 0.0f ? __builtin_amdgcn_rcpf(l_tot) : 0.0f;
-    if (p.lse != nullptr && g == 0 && my_row < Lq) {
-        long lidx = (p.cu_q != nullptr) ? ((long)h * p.lse_sh + p.cu_q[b] + my_row)
-                                        : ((long)b * p.Hq + h) * (long)p.Lq + my_row;
-        p.lse[lidx] = __builtin_amdgcn_logf(l_tot) + m_run;   // v_log_f32 is log2
-    }
-    // all waves are past the last tile barrier: the staging LDS is free
-    unsigned char *obuf = smem + wave * (32 * D * 2);
-    // per-channel epilogue factors, fetched per 32-wide d tile as straight-line batches of 16-byte
-    // vectors (a per-element "load if non-null" makes hipcc branch around every load and wait
-    // vmcnt(0) each time: 128 serial L2 round trips per workgroup)
-    const float *vsc = PV_FP8 ? p.v_scale + ((long)b * p.Hkv + hk) * D : nullptr;
-    const float *vmn = (p.v_mean != nullptr) ? p.v_mean + ((long)b * p.Hkv + hk) * D : nullptr;
-    // every factor of the tile is requested before the first one is used: one exposed memory latency per workgroup
-    // instead of one per 32-channel tile (the slot is idle for the co-resident workgroup's sake until this one retires)
-    v4f sc4[C::DT][4], mn4[C::DT][4];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; dt++) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const v4f one = {1.0f, 1.0f, 1.0f, 1.0f};
-            sc4[dt][r4] = PV_FP8 ? *reinterpret_cast<const v4f *>(vsc + dt * 32 + 8 * r4 + 4 * g) : one;
-        }
-        if (vmn != nullptr) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) mn4[dt][r4] = *reinterpret_cast<const v4f *>(vmn + dt * 32 + 8 * r4 + 4 * g);
-        } else {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) { const v4f z = {0.0f, 0.0f, 0.0f, 0.0f}; mn4[dt][r4] = z; }
-        }
-    }
-#pragma unroll
-    for (int dt = 0; dt < C::DT; dt++) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const int d0 = dt * 32 + 8 * r4 + 4 * g;           // 4 consecutive d: regs 4*r4 .. 4*r4+3
-            float x[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                x[j] = o[dt][4 * r4 + j] * inv;
-                if (PV_FP8) x[j] *= sc4[dt][r4][j];
-                x[j] += mn4[dt][r4][j];
-            }
-            v2u pk;
-            if (p.out_dtype == DT_F16) {
-                pk[0] = (unsigned)f32_to_f16_rne(x[0]) | ((unsigned)f32_to_f16_rne(x[1]) << 16);
-                pk[1] = (unsigned)f32_to_f16_rne(x[2]) | ((unsigned)f32_to_f16_rne(x[3]) << 16);
-            } else {
-                pk[0] = (unsigned)f32_to_bf16_rne(x[0]) | ((unsigned)f32_to_bf16_rne(x[1]) << 16);
-                pk[1] = (unsigned)f32_to_bf16_rne(x[2]) | ((unsigned)f32_to_bf16_rne(x[3]) << 16);
-            }
-            const int q8 = d0 >> 2;                             // 8-byte chunk index in the row
-            const int Q = (q8 >> 1) ^ (n & 7);                 // 16-B chunk, XOR-swizzled by row
-            *reinterpret_cast<v2u *>(obuf + n * (D * 2) + Q * 16 + (q8 & 1) * 8) = pk;
-        }
-    }
-    // each wave transposes through its OWN 32-row region: its ds_writes and ds_reads execute in order, no workgroup barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-        constexpr int LPR = D * 2 / 16;          // lanes per row (16 B each)
-        constexpr int RPP = 64 / LPR;            // rows per pass
-        unsigned char *obase = reinterpret_cast<unsigned char *>(p.o) + 2 * o_off;
-#pragma unroll
-        for (int pass = 0; pass < 32 / RPP; pass++) {
-            const int r = pass * RPP + lane / LPR, Q = lane % LPR;
-            const v4u val = *reinterpret_cast<const v4u *>(obuf + r * (D * 2) + (Q ^ (r & 7)) * 16);
-            const int grow = row0 + r;
-            if (grow < Lq) *reinterpret_cast<v4u *>(obase + 2 * ((long)grow * p.o_sl) + Q * 16) = val;
-        }
-    }
-#if SAGE_ATTN_TRACE
-    SAGE_TSTAMP(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SAGE_TSTAMP(7);
-    if (wave == 0 && bid < kAttnTraceWgs) {
-        if (lane < 8) g_attn_trace[16 * bid + lane] = ttrace[lane];
-        if (lane == 9) g_attn_trace[16 * bid + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
-        if (lane == 10) g_attn_trace[16 * bid + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        if (lane == 11) g_attn_trace[16 * bid + 11] = blockIdx.x;
-    }
-#endif
-    } while (0);
-    if (!pers) break;
-    // (the barrier also separates this item's LDS transposes from the next item's first tiles)
-    if (wave_s == 0) { const int t = resolve_ticket(); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) s_ticket[tpar] = t; }
-    __syncthreads();
-    bid = __builtin_amdgcn_readfirstlane(s_ticket[tpar]);      // (wave-uniform: everything derived from it stays in SGPRs)
-    tpar ^= 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One launch path for every instantiation: the > 64 KiB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize)
-// is issued once per instantiation and device, not per launch.
-constexpr int kPersistMinRounds = 12;
-static thread_local int g_last_attn_grid = 0;       // workgroups of this host thread's last attention launch (sage_debug_last_attn_grid: tests)
-int last_attn_grid() { return g_last_attn_grid; }
-
-template <typename Kern>
-static hipError_t launch_kernel(Kern kern, int lds, const AttnParams &p, int nwork, hipStream_t stream, bool persist_ok = false)
-{
-    if (lds > 65536) {
-        static thread_local unsigned long long done_mask = 0;      // bit per device ordinal (thread-local: no locking needed)
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done_mask & bit)) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            done_mask |= bit;
-        }
-    }
-    AttnParams pp = p;
-    int grid = nwork;
-    // Persistent launch (AttnParams::sched, a zeroed counter block of the caller; non-causal unmasked kernels): as many workgroups as the
-    // device holds at once take the logical workgroup indices 0 .. nwork - 1 from 32 ticket queues (see the kernel).  Worth it from twelve
-    // rounds of workgroups up -- one item must be small against the few per cent the XCDs differ by, or nothing can be evened out: with
-    // eight rounds of equal items (B2 H32 N8192 non-causal) the tickets cost 1 % -- anything else is an ordinary launch.
-    if (pp.sched != nullptr) {
-        unsigned *sched = pp.sched;
-        pp.sched = nullptr;
-        if (persist_ok && (nwork & 7) == 0) {
-            struct Occ { const void *k; int dev; int slots; };
-            static thread_local Occ cache[16];
-            static thread_local int ncache = 0;
-            int dev = 0, slots = -1;
-            hipError_t e = hipGetDevice(&dev);
-            if (e != hipSuccess) return e;
-            const void *kp = reinterpret_cast<const void *>(kern);
-            for (int c = 0; c < ncache; c++) if (cache[c].k == kp && cache[c].dev == dev) slots = cache[c].slots;
-            if (slots < 0) {
-                int ncu = 0, per_cu = 0;
-                e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-                if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, 256, lds);
-                if (e != hipSuccess) return e;
-                slots = ncu * per_cu;
-                if (ncache < 16) cache[ncache++] = Occ{kp, dev, slots};
-            }
-            if (slots > 0 && (slots & 31) == 0 && nwork >= kPersistMinRounds * slots) { pp.sched = sched; pp.nwg = nwork; grid = slots; }
-        }
-    }
-    g_last_attn_grid = grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, pp);
-    return hipGetLastError();
-}
-
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH>
-static hipError_t launch_one(const AttnParams &p, int nwork, hipStream_t stream)
-{
-    using C = TileCfg<D, PV_FP8, NH>;
-    constexpr int lds = C::LDS_BYTES;
-    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, KTHREAD, TWO_LEVEL, NH>, lds, p, nwork, stream, !CAUSAL);
-}
-
-template <int D, bool PV_FP8, int NH>
-static hipError_t launch_d(const AttnParams &p, int nwork, bool causal, bool kthread, bool two_level, hipStream_t s)
-{
-#define SAGE_CASE(C_, K_, T_) if (causal == C_ && kthread == K_ && two_level == T_) return launch_one<D, PV_FP8, C_, K_, T_, NH>(p, nwork, s);
-    SAGE_CASE(false, false, false) SAGE_CASE(false, false, true)
-    SAGE_CASE(true, false, false)  SAGE_CASE(true, false, true)
-    SAGE_CASE(false, true, false)  SAGE_CASE(false, true, true)
-    SAGE_CASE(true, true, false)   SAGE_CASE(true, true, true)
-#undef SAGE_CASE
-    return hipErrorInvalidValue;
-}
-
-template <int D, int MASK>
-static hipError_t launch_masked(const AttnParams &p, int nwork, hipStream_t stream)
-{
-    using C = TileCfg<D, false, 1>;
-    return launch_kernel(sage_attn_kernel<D, false, false, false, true, 1, MASK>, C::LDS_BYTES, p, nwork, stream);
-}
-
-template <int D, bool PV_FP8, bool CAUSAL, int QF>
-static hipError_t launch_fused_q_one(const AttnParams &p, int nwork, hipStream_t stream)
-{
-    // FP8 PV: two-level accumulation; FP16 PV: straight FP32 accumulation (the entry points' defaults); tile shapes as launch_attn
-    constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
-    using C = TileCfg<D, PV_FP8, NH>;
-    return launch_kernel(sage_attn_kernel<D, PV_FP8, CAUSAL, true, PV_FP8, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream, !CAUSAL);
-}
-
-// q in fp16 / bf16, quantised PER BLOCK in the prologue (QF 3 / 4): the Triton-named API's kernels (FP16 PV, per-block K scales,
-// tile product folded into the FP32 output), dense or varlen
-template <int D, bool CAUSAL, int QF>
-static hipError_t launch_fused_qblock_one(const AttnParams &p, int nwork, hipStream_t stream)
-{
-    constexpr int NH = D == 64 ? SAGE_NH_F8 : 1;
-    using C = TileCfg<D, false, NH>;
-    return launch_kernel(sage_attn_kernel<D, false, CAUSAL, false, true, NH, 0, QF>, C::LDS_BYTES, p, nwork, stream, !CAUSAL);
-}
 
 // Causal dense grids: which (head, query block) item a workgroup takes -- sage_work_order.h (mapping, group-size rule, measurements).
 // Split-KV chunks (weights depend on the chunk), masked and varlen calls keep the head-major heavy-first order over contiguous runs.
@@ -1739,7 +25,7 @@ int work_order()
     return g_work_order;
 }
 void set_work_order_mode(int group) { g_work_order = group; }
-static inline int nheads_of_varlen(const AttnParams &q) { return q.Hq; }
+
 static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8, bool masked)
 {
     q.order_group = 0;
@@ -1747,7 +33,7 @@ static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8,
     q.order_left = 0;
     const int nheads = q.B * q.Hq;
     if (q.cu_q != nullptr && q.work_items != nullptr)             // varlen, device-built work list: bound of the dense-style grid over it
-        return 8 * ((nheads_of_varlen(q) & 7) * ((q.items_bound + 7) / 8) + (nheads_of_varlen(q) >> 3) * q.items_bound);
+        return 8 * ((q.Hq & 7) * ((q.items_bound + 7) / 8) + (q.Hq >> 3) * q.items_bound);
     if (q.cu_q != nullptr) return ((q.B * q.Hkv + 7) / 8) * 8 * q.group * q.nqblk;   // varlen: whole rounds of 8 (sequence, kv-head) units
     const int forced = work_order();
     if (!causal || masked || q.kv_split > 1 || q.nqblk <= 1 || forced == 0) return nheads * q.nqblk;
@@ -1759,69 +45,53 @@ static int set_work_order(AttnParams &q, bool causal, int head_dim, bool pv_fp8,
     return grid;
 }
 
+// the instantiation unit of (head_dim, PV format, FP8 score form)
+static hipError_t launch_unit(const AttnParams &p, int head_dim, bool pv_fp8, const AttnVariant &v, int nwork, const AttnLaunchOpts &o)
+{
+    if (head_dim == 128) {
+        if (!pv_fp8) return launch_attn_part<128, false, true>(p, v, nwork, o);
+        return o.fp8_exact ? launch_attn_part<128, true, false>(p, v, nwork, o) : launch_attn_part<128, true, true>(p, v, nwork, o);
+    }
+    if (head_dim == 64) {
+        if (!pv_fp8) return launch_attn_part<64, false, true>(p, v, nwork, o);
+        return o.fp8_exact ? launch_attn_part<64, true, false>(p, v, nwork, o) : launch_attn_part<64, true, true>(p, v, nwork, o);
+    }
+    return hipErrorInvalidValue;
+}
+
 // per-thread granularity, q in fp16 (q_dtype 0) / bf16 (1), quantised in the kernel prologue
-hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream)
+hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, bool pv_fp8, const AttnLaunchOpts &o)
 {
     AttnParams p = p_in;
     const int nwork = set_work_order(p, causal, head_dim, pv_fp8, false);
+    if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
-#define SAGE_FQ(D_, F_) do { if (q_dtype == DT_F16) return causal ? launch_fused_q_one<D_, F_, true, 1>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 1>(p, nwork, stream); \
-                             return causal ? launch_fused_q_one<D_, F_, true, 2>(p, nwork, stream) : launch_fused_q_one<D_, F_, false, 2>(p, nwork, stream); } while (0)
-    if (head_dim == 128) { if (pv_fp8) SAGE_FQ(128, true); else SAGE_FQ(128, false); }
-    if (head_dim == 64) { if (pv_fp8) SAGE_FQ(64, true); else SAGE_FQ(64, false); }
-#undef SAGE_FQ
-    return hipErrorInvalidValue;
+    const AttnVariant v = {causal, true, pv_fp8, 0, q_dtype == DT_F16 ? 1 : 2};
+    return launch_unit(p, head_dim, pv_fp8, v, nwork, o);
 }
 
-hipError_t launch_attn_fused_qblock(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, hipStream_t stream)
+hipError_t launch_attn_fused_qblock(const AttnParams &p_in, int head_dim, bool causal, int q_dtype, const AttnLaunchOpts &o)
 {
     AttnParams p = p_in;
     const int nwork = set_work_order(p, causal, head_dim, false, false);
+    if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (q_dtype != DT_F16 && q_dtype != DT_BF16) return hipErrorInvalidValue;
-#define SAGE_FQB(D_) do { if (q_dtype == DT_F16) return causal ? launch_fused_qblock_one<D_, true, 3>(p, nwork, stream) : launch_fused_qblock_one<D_, false, 3>(p, nwork, stream); \
-                          return causal ? launch_fused_qblock_one<D_, true, 4>(p, nwork, stream) : launch_fused_qblock_one<D_, false, 4>(p, nwork, stream); } while (0)
-    if (head_dim == 128) SAGE_FQB(128);
-    if (head_dim == 64) SAGE_FQB(64);
-#undef SAGE_FQB
-    return hipErrorInvalidValue;
+    const AttnVariant v = {causal, false, true, 0, q_dtype == DT_F16 ? 3 : 4};
+    return launch_unit(p, head_dim, false, v, nwork, o);
 }
 
 hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool causal, bool kthread,
-                       bool two_level, int mask_kind, hipStream_t stream)
+                       bool two_level, int mask_kind, const AttnLaunchOpts &o)
 {
     AttnParams p = p_in;
     const int nwork = set_work_order(p, causal, head_dim, pv_fp8, mask_kind != 0);
+    if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
-    if (mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, two-level
-        if (pv_fp8 || causal || kthread || (head_dim != 64 && head_dim != 128) || mask_kind < 1 || mask_kind > 3)
-            return hipErrorInvalidValue;
-        if (head_dim == 128) return mask_kind == 1 ? launch_masked<128, 1>(p, nwork, stream)
-                                  : mask_kind == 2 ? launch_masked<128, 2>(p, nwork, stream) : launch_masked<128, 3>(p, nwork, stream);
-        return mask_kind == 1 ? launch_masked<64, 1>(p, nwork, stream)
-             : mask_kind == 2 ? launch_masked<64, 2>(p, nwork, stream) : launch_masked<64, 3>(p, nwork, stream);
-    }
-    // keys per iteration: 128 where two workgroups still fit a CU's LDS, else 64
-    if (head_dim == 128) return pv_fp8 ? launch_d<128, true, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream)
-                                       : launch_d<128, false, 1>(p, nwork, causal, kthread, two_level, stream);
-    if (head_dim == 64) return pv_fp8 ? launch_d<64, true, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream)
-                                      : launch_d<64, false, SAGE_NH_F8>(p, nwork, causal, kthread, two_level, stream);
-    return hipErrorInvalidValue;
+    if (mask_kind != 0 && (pv_fp8 || causal || kthread || mask_kind < 1 || mask_kind > 3)) return hipErrorInvalidValue;
+    const AttnVariant v = {causal, kthread, mask_kind != 0 ? true : two_level, mask_kind, 0};
+    return launch_unit(p, head_dim, pv_fp8, v, nwork, o);
 }
 
 }  // namespace sage
-
-#if SAGE_ATTN_TRACE
-extern "C" __attribute__((visibility("default"))) int sage_debug_attn_trace(unsigned *dst_host, int words, int clear)
-{
-    const size_t bytes = (size_t)(words < 16 * sage::kAttnTraceWgs ? words : 16 * sage::kAttnTraceWgs) * sizeof(unsigned);
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (dst_host != nullptr && hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(sage::g_attn_trace), bytes) != hipSuccess) return -2;
-    if (clear) {
-        void *d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(sage::g_attn_trace)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned) * 16 * sage::kAttnTraceWgs) != hipSuccess) return -3;
-    }
-    return 0;
-}
-#endif

@@ -1,0 +1,5 @@
+// sage_attn_d128_f8x.hip -- instantiation unit of the attention kernel family (sage_attn_kernel.h): launch_attn_part<D, PV_FP8, SFOLD> = <128,true,false>
+#include "sage_attn_kernel.h"
+namespace sage {
+template hipError_t launch_attn_part<128,true,false>(const AttnParams &, const AttnVariant &, int, const AttnLaunchOpts &);
+}

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -34,13 +35,31 @@ int check_launch(hipError_t e, const char *what)
 
 struct MaskArg { const void *ptr; int kind; int64_t sb, sh, sq, sk; };
 
-// The one-shot launch attribute of sage_attn_launch_ws: a zeroed counter block for the NEXT attention launch issued by this host thread.
-thread_local unsigned *g_launch_ws = nullptr;
-unsigned *take_launch_ws()
+// SageLaunchAttr (nullable) -> the launch workspace and the launcher's options; the attributes are arguments of THIS call, nothing is kept
+struct LaunchAttr { unsigned *ws; sage::AttnLaunchOpts opts; unsigned *trace; int trace_wgs; };
+int read_attr(const SageLaunchAttr *attr, void *stream, bool takes_ws, LaunchAttr &out)
 {
-    unsigned *w = g_launch_ws;
-    g_launch_ws = nullptr;
-    return w;
+    out.ws = nullptr;
+    out.opts = sage::AttnLaunchOpts{static_cast<hipStream_t>(stream), false, false, nullptr};
+    out.trace = nullptr;
+    out.trace_wgs = 0;
+    if (attr == nullptr) return SAGE_OK;
+    SageLaunchAttr a{};
+    const size_t n = (attr->struct_bytes == 0 || attr->struct_bytes > sizeof(SageLaunchAttr)) ? sizeof(SageLaunchAttr) : attr->struct_bytes;
+    SAGE_REQUIRE(n >= 8, "SageLaunchAttr.struct_bytes = %u is smaller than its own header", attr->struct_bytes);
+    memcpy(&a, attr, n);
+    SAGE_REQUIRE((a.flags & ~(SAGE_ATTR_FP8_EXACT_SCORES | SAGE_ATTR_FORCE_PERSISTENT)) == 0, "unknown SageLaunchAttr.flags 0x%x", a.flags);
+    SAGE_REQUIRE(a.launch_ws == nullptr || (a.launch_ws_bytes >= sage::kAttnSchedBytes && (reinterpret_cast<uintptr_t>(a.launch_ws) & 127u) == 0),
+                 "the launch workspace is %d bytes, 128-byte aligned, zeroed (got %lld bytes at %p)", sage::kAttnSchedBytes,
+                 (long long)a.launch_ws_bytes, a.launch_ws);
+    SAGE_REQUIRE(!(a.flags & SAGE_ATTR_FORCE_PERSISTENT) || a.launch_ws != nullptr, "SAGE_ATTR_FORCE_PERSISTENT needs a launch workspace");
+    out.ws = takes_ws ? static_cast<unsigned *>(a.launch_ws) : nullptr;
+    out.opts.fp8_exact = (a.flags & SAGE_ATTR_FP8_EXACT_SCORES) != 0;
+    out.opts.force_persistent = takes_ws && (a.flags & SAGE_ATTR_FORCE_PERSISTENT) != 0;
+    out.opts.grid_out = a.grid_out;
+    out.trace = a.trace;
+    out.trace_wgs = a.trace != nullptr ? a.trace_wgs : 0;
+    return SAGE_OK;
 }
 
 int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -49,11 +68,12 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                 int B, int Hq, int Hkv, int Lq, int Lk, int D,
                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream,
+                int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr,
                 const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr,
                 const int32_t *work_items = nullptr, const int32_t *work_hdr = nullptr, int items_bound = 0)
 {
-    unsigned *const launch_ws = take_launch_ws();        // (consumed whatever happens below)
+    LaunchAttr la;
+    if (const int rc = read_attr(attr, stream, mask == nullptr, la)) return rc;
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d)", B, Hq, Hkv, Lq);
@@ -72,7 +92,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     SAGE_REQUIRE(!varlen || (cu_q && cu_k && cu_qs && cu_ks), "varlen needs cu_seqlens arrays");
 
     sage::AttnParams p{};
-    p.sched = launch_ws;
+    p.sched = la.ws; p.trace = la.trace; p.trace_wgs = la.trace_wgs;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.q_scale = q_scale; p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = cu_qs; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
@@ -115,8 +135,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                  "bad pv_accum %d", pv_accum);
     // FP16 PV: the kernel's TWO_LEVEL parameter selects the Triton kernel form (true) or the CUDA kernel form (false)
     const bool two_level = fp8 ? pv_accum == SAGE_PV_ACCUM_TWO_LEVEL : pv_accum == SAGE_PV_ACCUM_TRITON;
-    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, two_level, mask_kind,
-                                          static_cast<hipStream_t>(stream)), "sage_attn launch");
+    return check_launch(sage::launch_attn(p, D, fp8, is_causal != 0, kthread, two_level, mask_kind, la.opts), "sage_attn launch");
 }
 
 }  // namespace
@@ -562,27 +581,17 @@ SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t 
 }
 
 SAGE_API int64_t sage_attn_launch_ws_bytes(void) { return sage::kAttnSchedBytes; }
-SAGE_API int sage_debug_last_attn_grid(void) { return sage::last_attn_grid(); }
-
-SAGE_API int sage_attn_launch_ws(void *ws, int64_t bytes)
-{
-    SAGE_REQUIRE(ws == nullptr || (bytes >= sage::kAttnSchedBytes && (reinterpret_cast<uintptr_t>(ws) & 127u) == 0),
-                 "the launch workspace is %d bytes, 128-byte aligned, zeroed (got %lld bytes at %p)", sage::kAttnSchedBytes, (long long)bytes, ws);
-    g_launch_ws = static_cast<unsigned *>(ws);
-    return SAGE_OK;
-}
-
 SAGE_API int sage_attn_qk_int8_pv_f8(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
                             const float *q_scale, const float *k_scale, const float *v_scale, const float *v_mean,
                             int B, int Hq, int Hkv, int Lq, int Lk, int D,
                             int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
                             int is_causal, int qk_quant_gran, int q_warp,
-                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return attn_common(true, false, q, k, v_image, o, lse, q_scale, k_scale, v_scale, v_mean, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream);
+                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream, attr);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -591,11 +600,11 @@ SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const vo
                              int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                              int64_t o_sb, int64_t o_sh, int64_t o_sl,
                              int is_causal, int qk_quant_gran, int q_warp,
-                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+                             float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, v_mean, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream);
+                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream, attr);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -603,12 +612,12 @@ SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, c
                                     int64_t m_sb, int64_t m_sh, int64_t m_sq, int64_t m_sk,
                                     int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                     int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
-                                    int64_t o_sb, int64_t o_sh, int64_t o_sl, float sm_scale_log2, int out_dtype, void *stream)
+                                    int64_t o_sb, int64_t o_sh, int64_t o_sl, float sm_scale_log2, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     const MaskArg m{mask, mask_kind, m_sb, m_sh, m_sq, m_sk};
     return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
-                       0, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, SAGE_PV_ACCUM_TRITON, out_dtype, stream, &m);
+                       0, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, SAGE_PV_ACCUM_TRITON, out_dtype, stream, attr, &m);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, const void *v_image, void *o,
@@ -618,12 +627,12 @@ SAGE_API int sage_attn_qk_int8_pv_f16_varlen(const int8_t *q, const int8_t *k, c
                                     const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                     int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                     int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
-                                    int is_causal, float sm_scale_log2, int pv_accum, int out_dtype, void *stream)
+                                    int is_causal, float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return attn_common(false, true, q, k, v_image, o, nullptr, q_scale, k_scale, nullptr, nullptr,
                        cu_seqlens_q, cu_seqlens_k, cu_q_scale, cu_k_scale,
                        nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
-                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, nullptr, seq_order,
+                       is_causal, SAGE_GRAN_PER_BLOCK, 128, sm_scale_log2, pv_accum, out_dtype, stream, attr, nullptr, seq_order,
                        work_items, work_hdr, items_bound);
 }
 
@@ -632,9 +641,11 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
                           int B, int Hq, int Hkv, int Lq, int Lk, int D,
                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                          int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream, bool pv_fp8 = true)
+                          int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream, const SageLaunchAttr *attr,
+                          bool pv_fp8 = true)
 {
-    unsigned *const launch_ws = take_launch_ws();
+    LaunchAttr la;
+    if (const int rc = read_attr(attr, stream, kv_split <= 1, la)) return rc;       // (split launches take no launch workspace)
     SAGE_REQUIRE(q && k && v_image && o && k_scale && (v_scale || !pv_fp8), "null tensor pointer");
     SAGE_REQUIRE(kv_split >= 0 && (kv_split <= 1 || Hkv % kv_split == 0), "kv_split (%d) must divide the folded kv-head count (%d)", kv_split, Hkv);
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -647,7 +658,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
     SAGE_REQUIRE(k_sl % 16 == 0 && k_sh % 16 == 0 && k_sb % 16 == 0, "int8 k strides must be multiples of 16");
     SAGE_REQUIRE(o_sl % 8 == 0 && o_sh % 8 == 0 && o_sb % 8 == 0, "output strides must be multiples of 8 elements");
     sage::AttnParams p{};
-    p.sched = launch_ws;
+    p.sched = la.ws; p.trace = la.trace; p.trace_wgs = la.trace_wgs;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.k_scale = k_scale; p.v_scale = v_scale; p.v_mean = v_mean;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
@@ -662,8 +673,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = sm_scale_log2;
     p.kv_split = kv_split;
-    return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, pv_fp8, static_cast<hipStream_t>(stream)),
-                        "sage_attn_fused_q launch");
+    return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, pv_fp8, la.opts), "sage_attn_fused_q launch");
 }
 
 SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -671,10 +681,10 @@ SAGE_API int sage_attn_fused_q_pv_f8(const void *q, const int8_t *k, const void 
                                      int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                      int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                      int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+                                     int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return fused_q_common(q, k, v_image, o, lse, k_scale, v_scale, v_mean, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
-                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream);
+                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, attr);
 }
 
 SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse,
@@ -682,10 +692,10 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                                       int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                       int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+                                      int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return fused_q_common(q, k, v_image, o, lse, k_scale, nullptr, v_mean, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
-                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, false);
+                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, attr, false);
 }
 
 // q in fp16 / bf16, quantised per 128-row block in the kernel prologue (dense: cu_q == nullptr; varlen: packed tensors, B = nseq)
@@ -695,9 +705,10 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
                                int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                               int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+                               int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
-    unsigned *const launch_ws = take_launch_ws();
+    LaunchAttr la;
+    if (const int rc = read_attr(attr, stream, true, la)) return rc;
     const bool varlen = cu_q != nullptr;
     SAGE_REQUIRE(q && k && v_image && o && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -712,7 +723,7 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
     SAGE_REQUIRE(!varlen || (cu_k && cu_ks), "varlen needs cu_seqlens_k and the k scale prefix array");
     SAGE_REQUIRE(!varlen || lse == nullptr, "varlen returns no lse");
     sage::AttnParams p{};
-    p.sched = launch_ws;
+    p.sched = la.ws; p.trace = la.trace; p.trace_wgs = la.trace_wgs;
     p.q = q; p.k = k; p.v = v_image; p.o = o; p.lse = lse;
     p.k_scale = k_scale;
     p.cu_q = cu_q; p.cu_k = cu_k; p.cu_qs = nullptr; p.cu_ks = cu_ks; p.seq_order = varlen ? seq_order : nullptr;
@@ -731,18 +742,17 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = 1.0f;                 // sm_scale * log2(e) is folded into the quantised q (q_premul), as the reference's quantiser does
     p.q_premul = q_premul;
-    return check_launch(sage::launch_attn_fused_qblock(p, D, is_causal != 0, q_dtype, static_cast<hipStream_t>(stream)),
-                        "sage_attn_fused_qblock launch");
+    return check_launch(sage::launch_attn_fused_qblock(p, D, is_causal != 0, q_dtype, la.opts), "sage_attn_fused_qblock launch");
 }
 
 SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
                                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+                                           int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     return fused_qblock_common(q, k, v_image, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Hq, Hkv, Lq, Lk, D,
-                               q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, q_dtype, out_dtype, stream);
+                               q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, q_dtype, out_dtype, stream, attr);
 }
 
 SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,
@@ -750,12 +760,12 @@ SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k
                                                   const int32_t *seq_order, const int32_t *work_items, const int32_t *work_hdr, int items_bound,
                                                   int nseq, int max_seqlen_q, int Hq, int Hkv, int D,
                                                   int64_t q_sl, int64_t q_sh, int64_t k_sl, int64_t k_sh, int64_t o_sl, int64_t o_sh,
-                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream)
+                                                  int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
     SAGE_REQUIRE(cu_seqlens_q != nullptr, "varlen needs cu_seqlens_q");
     return fused_qblock_common(q, k, v_image, o, nullptr, k_scale, cu_seqlens_q, cu_seqlens_k, cu_k_scale, seq_order,
                                work_items, work_hdr, items_bound, nseq, Hq, Hkv, max_seqlen_q, 0, D, 0, q_sh, q_sl, 0, k_sh, k_sl, 0, o_sh, o_sl,
-                               is_causal, q_premul, q_dtype, out_dtype, stream);
+                               is_causal, q_premul, q_dtype, out_dtype, stream, attr);
 }
 
 SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
@@ -763,14 +773,13 @@ SAGE_API int sage_attn_fused_q_pv_f8_split(const void *q, const int8_t *k, const
                                            int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                            int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+                                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
-    (void)take_launch_ws();                              // split launches take no launch workspace
     SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
     SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
     SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);
     return fused_q_common(q, k, v_image, o_part, lse_part, k_scale, v_scale, v_mean, B, Hq * kv_split, Hkv * kv_split, Lq, Lk_chunk, D,
-                          q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream);
+                          q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream, attr);
 }
 
 SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, const void *v_image, void *o_part, float *lse_part,
@@ -778,15 +787,14 @@ SAGE_API int sage_attn_fused_q_pv_f16_split(const void *q, const int8_t *k, cons
                                             int B, int Hq, int Hkv, int kv_split, int Lq, int Lk_chunk, int D,
                                             int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                             int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream)
+                                            int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
 {
-    (void)take_launch_ws();                              // split launches take no launch workspace
     SAGE_REQUIRE(kv_split >= 2, "kv_split must be at least 2 (got %d)", kv_split);
     SAGE_REQUIRE(o_part && lse_part, "split-KV needs the partial output and log-sum-exp buffers");
     SAGE_REQUIRE(Lk_chunk % 64 == 0, "split-KV chunks are whole numbers of 64-key tiles (got %d keys)", Lk_chunk);
     return fused_q_common(q, k, v_image, o_part, lse_part, k_scale, nullptr, v_mean, B, Hq * kv_split, Hkv * kv_split, Lq, Lk_chunk, D,
                           q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, kv_split, stream,
-                          false);
+                          attr, false);
 }
 
 SAGE_API int sage_merge_states(float *o_acc, float *lse_acc, const void *o_new, const float *lse_new, void *o_out,

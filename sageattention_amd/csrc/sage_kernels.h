@@ -50,16 +50,25 @@ struct AttnParams {
     int order_group;          // set by the launchers (sage_attn.hip set_work_order): causal dense work order, heads per group; 0 = head-major
     int order_fold;           // 1: single-round grid, pair the i-th longest with the i-th shortest block on a CU
     int order_left;           // (B * Hq) % 8 heads whose query blocks are dealt to all eight XCDs
+    unsigned *trace;          // -DSAGE_ATTN_TRACE=1 builds (tools/attn_trace.py): 16 words per logical workgroup, nullable; ignored otherwise
+    int trace_wgs;
 };
 
+// launch attributes of an attention call that are not kernel parameters (the C ABI's SageLaunchAttr, include/sage_gfx950.h)
+struct AttnLaunchOpts {
+    hipStream_t stream;
+    bool fp8_exact;          // FP8 PV: the exact score form (separate bias subtraction) instead of the folded one
+    bool force_persistent;   // take the ticket queues whatever the number of rounds (tests; AttnParams::sched must be set)
+    int *grid_out;           // nullable (host): receives the number of workgroups launched
+};
 // mask_kind: 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16-PV, per-block scales, non-causal only)
 hipError_t launch_attn(const AttnParams &p, int head_dim, bool pv_fp8, bool causal, bool kthread,
-                       bool two_level, int mask_kind, hipStream_t stream);
+                       bool two_level, int mask_kind, const AttnLaunchOpts &o);
 // q in fp16 / bf16, quantised per-thread in the kernel prologue; dense only.  FP8 PV: two-level accumulation; FP16 PV: FP32 accumulation
-hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, hipStream_t stream);
+hipError_t launch_attn_fused_q(const AttnParams &p, int head_dim, bool causal, int q_dtype, bool pv_fp8, const AttnLaunchOpts &o);
 // q in fp16 / bf16, quantised per 128-row block in the prologue after the multiplication by p.q_premul; FP16 PV in the Triton kernels'
 // form, per-block k scales; dense or varlen (p.cu_q)
-hipError_t launch_attn_fused_qblock(const AttnParams &p, int head_dim, bool causal, int q_dtype, hipStream_t stream);
+hipError_t launch_attn_fused_qblock(const AttnParams &p, int head_dim, bool causal, int q_dtype, const AttnLaunchOpts &o);
 
 // causal dense work order of the 128-row kernels: -1 grouped / folded by grid size, 0 head-major, n groups of n heads (SAGE_ORDER_GROUP)
 int work_order();
@@ -184,7 +193,6 @@ struct PrepassParams {
     int nseq;                 // number of sequences (segments >= nseq are gaps)
 };
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t stream);
-int last_attn_grid();
 hipError_t launch_debug_spin(int ms, int nwg, hipStream_t stream);
 
 // ---- LSE merge of partial attention states (sequence-parallel callers) -----------------------------

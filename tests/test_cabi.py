@@ -40,14 +40,14 @@ def test_argument_errors_do_not_need_a_gpu():
     rc = lib.sage_quant_qk_int8(p + 2, None, p, p, 1, 1, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 128, 128, 1, 0, 0, 1.0, 0, None)
     assert rc == -1 and b"aligned" in lib.sage_last_error()
     # Hq not divisible by Hkv
-    rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None)
+    rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None, None)
     assert rc == -1 and b"divisible" in lib.sage_last_error()
     with pytest.raises(ValueError):
         _cabi.check(rc, "x")
     # fused-Q attention: q dtype code, kv head count, strides
-    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 128, 0, 0, 128, 0, 0, 128, 0, 1.0, 7, 0, None)
+    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 128, 0, 0, 128, 0, 0, 128, 0, 1.0, 7, 0, None, None)
     assert rc == -1 and b"q_dtype" in lib.sage_last_error()
-    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 132, 0, 0, 128, 0, 0, 128, 0, 1.0, 0, 0, None)
+    rc = lib.sage_attn_fused_q_pv_f8(p, p, p, p, None, p, p, None, 1, 2, 2, 16, 16, 128, 0, 0, 132, 0, 0, 128, 0, 0, 128, 0, 1.0, 0, 0, None, None)
     assert rc == -1 and b"q strides" in lib.sage_last_error()
     # LSE merge: head_dim must be a multiple of 8, pointers non-null
     rc = lib.sage_merge_states(p, p, p, p, None, 1, 1, 4, 12, 0, 0, 12, 0, 0, 0, 0, 0, None)
@@ -56,11 +56,11 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b"null" in lib.sage_last_error()
     # varlen attention needs its prefix arrays
     rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, None, None, None, None, None, None, None, 0, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
-                                             0, 1.0, 1, 0, None)
+                                             0, 1.0, 1, 0, None, None)
     assert rc == -1 and b"varlen" in lib.sage_last_error()
     # a work list comes with its header and a positive bound
     rc = lib.sage_attn_qk_int8_pv_f16_varlen(p, p, p, p, p, p, p, p, p, p, None, p, None, 4, 1, 16, 2, 2, 64, 128, 64, 128, 64, 128, 64,
-                                             0, 1.0, 1, 0, None)
+                                             0, 1.0, 1, 0, None, None)
     assert rc == -1 and b"work list" in lib.sage_last_error()
     # the varlen plan: sequence count, and the work list needs the attention kernel's block sizes
     rc = lib.sage_varlen_plan(p, p, 5000, 0, 128, 64, 0, 8, 8, 128, 0, None, p, p, None, None, None, None, None)
@@ -77,24 +77,44 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1
 
 
-def test_launch_workspace_attribute_is_checked_and_one_shot():
-    """sage_attn_launch_ws: size and alignment are checked; the attribute is consumed by the next attention call of the thread even when
-    that call fails its argument checks (no launch, no GPU needed): the call after it must not see it."""
+def test_launch_attributes_are_checked_arguments():
+    """SageLaunchAttr travels with the call it belongs to: workspace size / alignment, unknown flags and a force flag without a workspace
+    are refused BEFORE the tensor arguments are looked at (so no GPU is needed to see it); a shorter struct (an older caller) is accepted;
+    NULL is the default.  The library exports no setter any more."""
     lib = _cabi.load()
     n = int(lib.sage_attn_launch_ws_bytes())
     assert n == 32 * 128
+    assert not hasattr(lib, "sage_attn_launch_ws") and not hasattr(lib, "sage_debug_last_attn_grid")
     buf = ctypes.create_string_buffer(n + 256)
     p = (ctypes.addressof(buf) + 127) & ~127
-    assert lib.sage_attn_launch_ws(p, n - 1) == -1 and b"launch workspace" in lib.sage_last_error()
-    assert lib.sage_attn_launch_ws(p + 64, n) == -1
-    assert lib.sage_attn_launch_ws(None, 0) == 0
-    assert lib.sage_attn_launch_ws(p, n) == 0
-    # a failing attention call (Hq not divisible by Hkv) consumes it ...
-    rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None)
-    assert rc == -1
-    # ... (the library offers no getter: the attribute is write-only by design; that it is gone is checked on the GPU, where a launch
-    # without a fresh attribute must be an ordinary one -- tests/test_gpu_parity.py)
-    assert lib.sage_attn_launch_ws(None, 0) == 0
+
+    def call(attr):      # Hq not divisible by Hkv: the call fails its argument checks either way, never launches
+        rc = lib.sage_attn_qk_int8_pv_f16(p, p, p, p, None, p, p, None, 1, 3, 2, 16, 16, 64, 0, 0, 64, 0, 0, 64, 0, 0, 64, 0, 1, 128, 1.0, 1, 0, None,
+                                          None if attr is None else ctypes.byref(attr))
+        return rc, lib.sage_last_error()
+
+    def attr(**kw):
+        a = _cabi.SageLaunchAttr()
+        a.struct_bytes = ctypes.sizeof(a)
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_)
+        return a
+
+    assert call(None) == (-1, lib.sage_last_error()) and b"divisible" in lib.sage_last_error()
+    rc, msg = call(attr(launch_ws=p, launch_ws_bytes=n - 1))
+    assert rc == -1 and b"launch workspace" in msg
+    rc, msg = call(attr(launch_ws=p + 64, launch_ws_bytes=n))
+    assert rc == -1 and b"launch workspace" in msg
+    rc, msg = call(attr(flags=0x80))
+    assert rc == -1 and b"flags" in msg
+    rc, msg = call(attr(flags=_cabi.ATTR_FORCE_PERSISTENT))
+    assert rc == -1 and b"FORCE_PERSISTENT" in msg
+    rc, msg = call(attr(struct_bytes=4))
+    assert rc == -1 and b"struct_bytes" in msg
+    for ok in (attr(launch_ws=p, launch_ws_bytes=n), attr(flags=_cabi.ATTR_FP8_EXACT_SCORES), attr(struct_bytes=8),
+               attr(struct_bytes=0, launch_ws=p, launch_ws_bytes=n)):
+        rc, msg = call(ok)
+        assert rc == -1 and b"divisible" in msg          # past the attribute checks
 
 
 def test_v_image_bytes():

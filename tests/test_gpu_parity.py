@@ -3,8 +3,11 @@ vectors and fp32 SDPA.  Run on an MI355X:  python -m pytest tests -m gpu -q
 
 Bars (stated here, used below):
   * INT8 tensors, scales, FP8 bytes, fp16 V image: BIT-EXACT vs the oracle / the reference fixtures.
-  * attention output vs the oracle on identical quantised operands: max|diff| <= 2e-3 * max|o|
-    (differences: v_exp_f32 vs exp2f, FP32 summation order, FP32 instead of FP16 tile products).
+  * attention output vs the oracle on identical quantised operands AND THE SAME SCHEDULE: max|diff| <= 2e-3 * max|o|
+    (differences: v_exp_f32 vs exp2f, FP32 summation order, FP32 instead of FP16 tile products).  "Same schedule": the oracle mode
+    that mirrors the route rounding for rounding -- FP8 score form folded / exact (oracle score_mode), split-KV (_split_oracle).
+  * an FP8 schedule variant that is a DEFAULT route (the folded score form): additionally rel-RMS <= 1e-2 against the exact form and
+    cos / rel-RMSE vs fp32 SDPA within 1e-4 / 1e-3 of the exact form's (test_fp8_score_forms_*).
   * vs the reference Triton outputs (golden fixtures): max|diff| <= 2e-3 * max|o| (fp16),
     one bf16 ulp more for bf16 outputs (the CPU interpreter truncates fp32->bf16).
   * vs fp32 SDPA on randn inputs: cos >= 0.9995 / rel-RMSE <= 2% (FP16 PV), cos >= 0.999 / <= 5% (FP8 PV).
@@ -22,8 +25,13 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     import sageattention_amd as sa
-    from sageattention_amd import _cabi, quant as sq
+    from sageattention_amd import _cabi, ops as sa_ops, quant as sq
     DEV = torch.device("cuda:0")
+    # the FP8 score form the product runs by default ("folded"; SAGE_FP8_SCORES=exact runs the whole suite on the exact form): every FP8
+    # comparison below is kernel(form) against oracle(SAME form) at 2e-3 * max|o|, the one rule of DESIGN.md 4
+    SCORES = "exact" if sa_ops._FP8_EXACT else "folded"
+else:
+    SCORES = "folded"
 
 REPORT = {}
 
@@ -220,7 +228,7 @@ def test_smooth_v_paths_vs_oracle_and_sdpa(oracle_mod, pv, causal):
         vm = sq.channel_mean(vd).float().cpu().numpy()
     torch.cuda.synchronize()
     ref, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv=pv,
-                                          qk_quant_gran="per_warp", km=km, smooth_v=True, vm=vm)
+                                          qk_quant_gran="per_warp", km=km, smooth_v=True, vm=vm, fp8_scores=SCORES)
     got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
     scale = float(np.abs(ref).max())
     assert np.abs(got - ref).max() <= 2e-3 * scale + 2 ** -11 * scale
@@ -242,7 +250,15 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("pv", ["f8_two", "f8_single", "f16_two", "f16_single"])
+PV_ACCUM = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f8x_two": "fp32+fp32", "f8x_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}
+
+
+def _scores_of(pv):
+    """f8_*: FP8 PV in the product's default score form (folded); f8x_*: the exact form (fp8_scores="exact"); None for FP16 PV."""
+    return None if pv.startswith("f16") else ("exact" if pv.startswith("f8x") else "folded")
+
+
+@pytest.mark.parametrize("pv", ["f8_two", "f8_single", "f8x_two", "f8x_single", "f16_two", "f16_single"])
 @pytest.mark.parametrize("gran", ["per_block", "per_warp", "per_thread"])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -251,15 +267,18 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     O = oracle_mod
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=100 + [c[0] for c in CASES].index(name), kbias=1.5)
     fp8 = pv.startswith("f8")
+    scores = _scores_of(pv)
     # the K mean is host plumbing (torch, as in the reference): hand the oracle the very same km
     km = util.bits(sq.channel_mean(k.to(DEV)))
     o_bits, lse_ref, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal,
                                             pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km,
-                                            warpq=16 if (pv == "f16_two" and D == 128) else 32)   # core.py:602
+                                            warpq=16 if (pv == "f16_two" and D == 128) else 32,   # core.py:602
+                                            fp8_scores=scores or "exact", single_level=pv.endswith("single") and fp8)
     # same operands through the HIP kernels
     fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
-    accum = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}[pv]
-    o, lse = fn(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=causal, qk_quant_gran=gran, pv_accum_dtype=accum, return_lse=True)
+    accum = PV_ACCUM[pv]
+    kw = dict(fp8_scores=scores) if fp8 else {}
+    o, lse = fn(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=causal, qk_quant_gran=gran, pv_accum_dtype=accum, return_lse=True, **kw)
     torch.cuda.synchronize()
     got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
     assert np.isfinite(got).all()
@@ -282,7 +301,7 @@ def test_sm90_entry_point_scale_groups_vs_oracle(oracle_mod, case, causal, gran)
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=300 + Lq, kbias=1.5)
     km = util.bits(sq.channel_mean(k.to(DEV)))
     o_bits, lse_ref, aux = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
-                                                     qk_quant_gran=gran, return_lse=True, km=km, warpq=16, blkk=128)
+                                                     qk_quant_gran=gran, return_lse=True, km=km, warpq=16, blkk=128, fp8_scores=SCORES)
     o, lse = sa.sageattn_qk_int8_pv_fp8_cuda_sm90(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=causal, qk_quant_gran=gran,
                                                   pv_accum_dtype="fp32+fp32", return_lse=True)
     torch.cuda.synchronize()
@@ -351,12 +370,58 @@ def test_long_sequence_32k_vs_oracle(oracle_mod):
     torch.cuda.synchronize()
     km = util.bits(sq.channel_mean(kd))
     ref, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 1, is_causal=True, pv="f8",
-                                          qk_quant_gran="per_thread", km=km)
+                                          qk_quant_gran="per_thread", km=km, fp8_scores=SCORES)
     got, ref = o.float().cpu().numpy(), util.f32(ref, 1)
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
     REPORT["kernel_vs_oracle/n32768_causal_f8"] = dict(max_abs=err, max_o=scale)
     assert err <= 2e-3 * scale + 2 ** -8 * scale
+
+
+# ------------------------------------------------------------------------------------------------ FP8 score forms (the one rule)
+FORM_CASES = [
+    # name,                       B  Hq Hkv  Lq    Lk    D   dt causal kbias
+    ("c3_like_n2048_d128_causal", 1, 8, 8, 2048, 2048, 128, 1, True, 0.0),
+    ("c5_like_n4400_d64",         1, 6, 6, 4400, 4400,  64, 1, False, 0.0),
+    ("biased_k_n1024_d128",       2, 4, 2, 1024, 1024, 128, 0, True, 5.0),
+    ("short_n300_d128_causal",    2, 4, 4,  300,  300, 128, 0, True, 1.0),
+    ("short_n512_d64",            2, 4, 2,  512,  512,  64, 0, False, 1.0),
+    ("short_n333_d64_cross",      2, 4, 4,  200,  333,  64, 1, False, 2.0),
+]
+
+
+@pytest.mark.parametrize("case", FORM_CASES, ids=[c[0] for c in FORM_CASES])
+def test_fp8_score_forms_folded_default_vs_exact(oracle_mod, case):
+    """The folded score form is a DEFAULT FP8 route under three clauses (VERDICT r4 / DESIGN.md 4): (i) kernel(folded) meets oracle(folded) --
+    the oracle mode that mirrors it rounding for rounding -- at 2e-3 * max|o|, and kernel(exact) meets oracle(exact); (ii) folded against
+    exact: rel-RMS <= 1e-2 (kernel vs kernel here, oracle vs oracle on the CPU in tests/test_oracle_golden.py); (iii) cos / rel-RMSE vs
+    fp32 SDPA within 1e-4 / 1e-3 of the exact form's.  The exact form stays the one pinned to the reference formula."""
+    name, B, Hq, Hkv, Lq, Lk, D, dt, causal, kbias = case
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=900 + Lq, kbias=kbias)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = {}
+    for form in ("folded", "exact"):
+        out[form] = sa.sageattn(qd, kd, vd, is_causal=causal, fp8_scores=form)
+    o_default = sa.sageattn(qd, kd, vd, is_causal=causal)
+    torch.cuda.synchronize()
+    assert torch.equal(o_default, out[SCORES]), "the default form is the one SAGE_FP8_SCORES names (folded unless set)"
+    km = util.bits(sq.channel_mean(kd))
+    truth = util.sdpa_f32(q, k, v, causal).numpy()
+    tn = float(np.sqrt((truth ** 2).mean()))
+    stats = {}
+    for form in ("folded", "exact"):
+        got = out[form].float().cpu().numpy()
+        ref, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
+                                              qk_quant_gran="per_thread", km=km, fp8_scores=form)
+        _assert_vs_oracle(f"score_forms/{name}/{form}", got, ref, dt)                                       # (i)
+        stats[form] = (util.cos_sim(got, truth), util.rmse(got, truth) / tn)
+    a, b = out["folded"].float().cpu().numpy(), out["exact"].float().cpu().numpy()
+    rel_rms = float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+    REPORT[f"score_forms/{name}"] = dict(rel_rms_folded_vs_exact=rel_rms, max_abs=float(np.abs(a - b).max()), max_o=float(np.abs(b).max()),
+                                         cos_folded=stats["folded"][0], cos_exact=stats["exact"][0],
+                                         rel_rmse_folded=stats["folded"][1], rel_rmse_exact=stats["exact"][1])
+    assert rel_rms <= 1e-2, rel_rms                                                                          # (ii)
+    assert abs(stats["folded"][0] - stats["exact"][0]) <= 1e-4 and abs(stats["folded"][1] - stats["exact"][1]) <= 1e-3, stats   # (iii)
 
 
 # ------------------------------------------------------------------------------------------------ golden (reference outputs)
@@ -648,7 +713,7 @@ def test_config3_full_vs_oracle(oracle_mod):
     assert torch.equal(o_default, o), "sageattn() dispatches to the FP8 two-level path"
     km = util.bits(sq.channel_mean(kd))
     ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 1, is_causal=True, pv="f8",
-                                                qk_quant_gran="per_thread", return_lse=True, km=km)
+                                                qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=SCORES)
     _assert_vs_oracle("c3_f8pv_b2h32n8192d128_causal", o.float().cpu().numpy(), ref, 1)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
 
@@ -696,7 +761,7 @@ def test_config5_cogvideox_shape_vs_oracle(oracle_mod):
     b = 1
     km = util.bits(sq.channel_mean(kd))[b:b + 1, hs]
     ref, _, _ = oracle_mod.sageattn_dense(util.bits(q[b:b + 1, hs]), util.bits(k[b:b + 1, hs]), util.bits(v[b:b + 1, hs]), 1,
-                                          is_causal=False, pv="f8", qk_quant_gran="per_thread", km=np.ascontiguousarray(km))
+                                          is_causal=False, pv="f8", qk_quant_gran="per_thread", km=np.ascontiguousarray(km), fp8_scores=SCORES)
     _assert_vs_oracle("c5_cogvideox_b2h48n17776d64", o[b:b + 1, hs].float().cpu().numpy(), ref, 1)
     truth = util.sdpa_f32(qd[b:b + 1, hs[:2]], kd[b:b + 1, hs[:2]], vd[b:b + 1, hs[:2]], False).cpu().numpy()
     got = o[b:b + 1, hs[:2]].float().cpu().numpy()
@@ -736,7 +801,7 @@ def _split_oracle(O, q, k, v, dt, S, km, causal=False):
     tensors), run the oracle's attention per key-range chunk with fp16 partial outputs, merge by log-sum-exp in float64.
     Causal: chunk s holds keys s*Lc .., so only the query rows >= s*Lc see it, top-left aligned against the chunk."""
     _, _, aux = O.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
-                                 qk_quant_gran="per_thread", km=km)
+                                 qk_quant_gran="per_thread", km=km, fp8_scores=SCORES)
     B, Hq, Lq, D = q.shape
     Lk = k.shape[2]
     Lc = Lk // S
@@ -752,7 +817,8 @@ def _split_oracle(O, q, k, v, dt, S, km, causal=False):
         ks = np.ascontiguousarray(aux["ks"][:, :, g0:g0 + int(gk.max()) + 1])
         o_s, lse_s = O.attn(np.ascontiguousarray(aux["q8"][:, :, r0:]), np.ascontiguousarray(aux["k8"][:, :, sl]),
                             np.ascontiguousarray(aux["v8"][:, :, sl]), aux["qs"], np.ascontiguousarray(aux["gq"][r0:]), ks, gk,
-                            causal=causal, c=aux["c"], pv_mode=O.PV_F8_TWO_LEVEL, out_dtype=0, v_scale=aux["vs"], return_lse=True)
+                            causal=causal, c=aux["c"], pv_mode=O.PV_F8_TWO_LEVEL, out_dtype=0, v_scale=aux["vs"], return_lse=True,
+                            score_mode=O.SCORES_EXACT if SCORES == "exact" else O.SCORES_FOLDED)
         parts[s, :, :, r0:] = util.f32(o_s, 0)
         lse[s, :, :, r0:] = lse_s
     m = lse.max(axis=0)
@@ -792,10 +858,11 @@ def test_split_kv_vs_split_oracle_and_sdpa(oracle_mod, case):
     assert (lse - lse1).abs().max().item() <= 2e-2           # same quantity through two summation orders (+ fp8 noise on l)
     # ... and against the UNSPLIT oracle, i.e. the reference algorithm itself.  A split changes which running maximum every P is
     # rounded to e4m3 against, so the two differ by FP8 rounding noise of P (2^-4 relative per element, averaged over the row), not
-    # by the 2e-3 of same-operand comparisons.  Stated bound (divergence list): rel-RMS <= 4e-2, max <= 8e-2 * max|o| (the FP8 bound vs fp32 SDPA is 5e-2);
-    # measured values are in the parity report.
+    # by the 2e-3 of same-operand comparisons: rel-RMS up to 2.8e-2 measured, beyond the 1e-2 a DEFAULT FP8 route may differ from the exact
+    # schedule by -- which is why FP8 split-KV is opt-in since round 5 (core._split_kv_plan).  Stated bound of the opt-in route (DESIGN.md 4,
+    # divergence list): rel-RMS <= 4e-2, max <= 8e-2 * max|o| (the FP8 bound vs fp32 SDPA is 5e-2); measured values are in the parity report.
     ref_u, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
-                                            qk_quant_gran="per_thread", km=km)
+                                            qk_quant_gran="per_thread", km=km, fp8_scores=SCORES)
     ref_u = util.f32(ref_u, dt)
     d_u = got - ref_u
     rel_rms = float(np.sqrt((d_u ** 2).mean()) / np.sqrt((ref_u ** 2).mean()))
@@ -952,18 +1019,21 @@ def test_random_shapes_vs_oracle(oracle_mod, seed):
     Lq = Lk if (causal and rng.random() < 0.7) else int(rng.integers(1, 420))
     dt = int(rng.integers(0, 2))
     gran = str(rng.choice(["per_block", "per_warp", "per_thread"]))
-    pv = str(rng.choice(["f8_two", "f8_single", "f16_two", "f16_single"]))
+    pv = str(rng.choice(["f8_two", "f8_single", "f8x_two", "f8x_single", "f16_two", "f16_single"]))
     layout = str(rng.choice(["HND", "NHD"]))
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
     fp8 = pv.startswith("f8")
     km = util.bits(sq.channel_mean(k.to(DEV)))
+    scores = _scores_of(pv)
     o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal,
                                                    pv="f8" if fp8 else "f16", qk_quant_gran=gran, return_lse=True, km=km,
-                                                   warpq=16 if (pv == "f16_two" and D == 128) else 32)
+                                                   warpq=16 if (pv == "f16_two" and D == 128) else 32, fp8_scores=scores or "exact",
+                                                   single_level=fp8 and pv.endswith("single"))
     fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
-    accum = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}[pv]
+    accum = PV_ACCUM[pv]
+    kw = dict(fp8_scores=scores) if fp8 else {}
     o, lse = fn(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout, is_causal=causal,
-                qk_quant_gran=gran, pv_accum_dtype=accum, return_lse=True)
+                qk_quant_gran=gran, pv_accum_dtype=accum, return_lse=True, **kw)
     torch.cuda.synchronize()
     got, ref = to_hnd(o, layout).float().cpu().numpy(), util.f32(o_bits, dt)
     desc = f"B{B} Hq{Hq} Hkv{Hkv} Lq{Lq} Lk{Lk} D{D} dt{dt} causal{causal} {gran} {pv} {layout}"
@@ -1259,18 +1329,21 @@ def test_varlen_with_empty_sequences(causal):
 
 
 def test_persistent_launches_are_bit_identical_and_really_taken(monkeypatch):
-    """Large non-causal calls hand the attention launch a zeroed counter block (sage_attn_launch_ws) and run as persistent launches: fewer
-    workgroups than work items, the same output bits as the ordinary launch; causal calls and small calls stay ordinary launches; the
-    attribute does not outlive the call it was set for."""
+    """Large non-causal calls hand the attention launch a zeroed counter block (SageLaunchAttr.launch_ws) and run as persistent launches:
+    fewer workgroups than work items, the same output bits as the ordinary launch; causal calls and small calls stay ordinary launches; the
+    attribute is an argument of its call -- a call without it is an ordinary launch whatever came before."""
+    import ctypes
     from sageattention_amd import ops
-    lib = sq._cabi.load()
+    probe = ctypes.c_int32(-1)
+    monkeypatch.setattr(ops, "grid_probe", probe)
     g = torch.Generator().manual_seed(77)
 
     def run(fn, on):
         monkeypatch.setattr(ops, "_PERSISTENT", on)
+        probe.value = -1
         out = fn()
         torch.cuda.synchronize()
-        return out, int(lib.sage_debug_last_attn_grid())
+        return out, int(probe.value)
 
     # dense, FP8 PV (sageattn) at D = 64 (three workgroups per CU: 768 at once) and D = 128 (512), FP16 PV and the Triton-named API:
     # twelve rounds of workgroups = 2 * 36 * 128 = 9216 / 2 * 24 * 128 = 6144 work items
@@ -1288,15 +1361,15 @@ def test_persistent_launches_are_bit_identical_and_really_taken(monkeypatch):
         _, gs = run(lambda: api(qc, kc, vc, is_causal=False), True)           # eight rounds at most: an ordinary launch
         assert gs == 2 * H * 32
         del q, k, v, qc, kc, vc
-    # a launch without a fresh attribute is an ordinary one (the attribute of the previous call was consumed by it)
+    # a launch without the attribute is an ordinary one (nothing of the previous call's attribute is left anywhere)
     q, k, v = (torch.randn(2, 24, 16384, 128, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3))
     _, g1 = run(lambda: sa.sageattn(q, k, v), True)
+    orig_ws = ops.attn_launch_ws
     monkeypatch.setattr(ops, "attn_launch_ws", lambda *a, **kw: None)
-    o0 = sa.sageattn(q, k, v)
-    torch.cuda.synchronize()
-    assert int(lib.sage_debug_last_attn_grid()) == 6144 and g1 < 6144
-    monkeypatch.undo()
-    del q, k, v, o0
+    _, g0 = run(lambda: sa.sageattn(q, k, v), True)
+    assert g0 == 6144 and g1 < 6144
+    monkeypatch.setattr(ops, "attn_launch_ws", orig_ws)
+    del q, k, v
     # packed batches, non-causal: 16 heads x 52000 rows
     lens = [19000, 300, 17000, 129, 15571]
     q = torch.randn(sum(lens), 16, 128, generator=g).to(torch.bfloat16).to(DEV)

@@ -167,3 +167,114 @@ def test_varlen_200_launches_on_two_streams_are_bit_identical(route, causal):
         torch.cuda.synchronize()
         bad += int(not torch.equal(o1, first)) + int(not torch.equal(o2, first))
     assert bad == 0, f"{bad} of 200 varlen launches differ from the first"
+
+
+# ------------------------------------------------------------------------------------------------ persistent launches (ticket queues)
+# name, entry point, kwargs, (B, Hq, Hkv, Lq, Lk, D, dtype): non-causal calls of at least two rounds of workgroups (D = 128: 2 x 512 items,
+# D = 64: 2 x 768), which ops.force_persistent sends down the ticket route (SAGE_ATTR_FORCE_PERSISTENT; the default threshold is twelve
+# rounds, i.e. shapes five times larger -- the same kernel, loop and queues)
+PERSISTENT_CASES = [
+    ("f8_d128_fusedq_bf16", "sageattn", dict(), (1, 8, 8, 16384, 16384, 128, BF16)),
+    ("f8_d64_fusedq_f16", "sageattn", dict(), (1, 12, 12, 16384, 16384, 64, F16)),
+    ("f8_d64_int8q_per_thread", "fp8", dict(qk_quant_gran="per_thread", pv_accum_dtype="fp32+fp32", fuse_q_quant=False), (1, 12, 6, 16384, 16384, 64, BF16)),
+    ("f8_d128_int8q_per_warp_single_exact", "fp8", dict(qk_quant_gran="per_warp", pv_accum_dtype="fp32", fp8_scores="exact"), (1, 8, 8, 16384, 16384, 128, F16)),
+    ("f16_d128_triton_form", "triton", dict(), (1, 8, 8, 16384, 16384, 128, F16)),
+    ("f16_d64_cuda_form_gqa", "fp16", dict(qk_quant_gran="per_thread", pv_accum_dtype="fp32"), (1, 12, 4, 16384, 16384, 64, BF16)),
+]
+
+
+@pytest.fixture
+def forced_persistent(monkeypatch):
+    import ctypes
+    from sageattention_amd import ops
+    probe = ctypes.c_int32(-1)
+    monkeypatch.setattr(ops, "grid_probe", probe)
+    monkeypatch.setattr(ops, "force_persistent", True)
+    monkeypatch.setattr(ops, "_PERSISTENT", True)
+    return ops, probe
+
+
+def _soak(fn, want, n=100):
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    bad = 0
+    for i in range(n):
+        with torch.cuda.stream(side):
+            if i % 4 == 0:
+                (a @ a).sum()                      # a competing kernel on the other stream
+            o2 = fn()
+        o1 = fn()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(o1, want)) + int(not torch.equal(o2, want))
+    return bad
+
+
+@pytest.mark.parametrize("case", PERSISTENT_CASES, ids=[c[0] for c in PERSISTENT_CASES])
+def test_persistent_route_200_launches_on_two_streams_equal_the_ordinary_launch(route, forced_persistent, monkeypatch, case):
+    """The ticket-queue route of the large non-causal launches: 200 launches alternating between two streams beside a
+    competing GEMM, every call with a workspace of its own, each bit-identical to the ORDINARY launch of the same call; the probe confirms
+    that the route is really taken (fewer workgroups than work items) and really off for the reference run."""
+    ops, probe = forced_persistent
+    name, entry, kw, shape = case
+    q, k, v = _qkv(*shape, seed=11 + len(name))
+    fn = lambda: _fn(entry)(q, k, v, is_causal=False, **kw)
+    items = shape[0] * shape[1] * ((shape[3] + 127) // 128)
+    monkeypatch.setattr(ops, "_PERSISTENT", False)
+    want = fn()
+    torch.cuda.synchronize()
+    assert probe.value == items and torch.isfinite(want.float()).all()
+    monkeypatch.setattr(ops, "_PERSISTENT", True)
+    got = fn()
+    torch.cuda.synchronize()
+    assert 0 < probe.value < items and probe.value % 32 == 0, (probe.value, items)
+    assert torch.equal(got, want)
+    bad = _soak(fn, want)
+    assert bad == 0, f"{name}: {bad} of 200 persistent launches differ from the ordinary launch"
+
+
+def test_persistent_route_varlen_200_launches_equal_the_ordinary_launch(route, forced_persistent, monkeypatch):
+    """The packed (varlen) launch over the device-built work list on the ticket route: the logical grid comes from the plan's header on the
+    device, items differ in length by two orders of magnitude."""
+    ops, probe = forced_persistent
+    lens = [4096, 1, 640, 129, 3000, 64, 1500, 777, 2100]
+    total = sum(lens)
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(total, 16, 128, generator=g).to(BF16).to(DEV)
+    k = (torch.randn(total, 4, 128, generator=g) + torch.randn(1, 4, 128, generator=g)).to(BF16).to(DEV)
+    v = torch.randn(total, 4, 128, generator=g).to(BF16).to(DEV)
+    cu = torch.nn.functional.pad(torch.tensor(lens).cumsum(0), (1, 0)).to(torch.int32).to(DEV)
+    fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=False)
+    monkeypatch.setattr(ops, "_PERSISTENT", False)
+    want = fn()
+    torch.cuda.synchronize()
+    ordinary = probe.value
+    monkeypatch.setattr(ops, "_PERSISTENT", True)
+    got = fn()
+    torch.cuda.synchronize()
+    assert 0 < probe.value < ordinary and probe.value % 32 == 0, (probe.value, ordinary)
+    assert torch.equal(got, want)
+    bad = _soak(fn, want)
+    assert bad == 0, f"{bad} of 200 persistent varlen launches differ from the ordinary launch"
+
+
+def test_persistent_route_in_a_captured_graph_replays_identically(route, forced_persistent, monkeypatch):
+    """A persistent launch captured in a HIP graph: the workspace is allocated and zeroed inside the capture (a fill node in front of the
+    attention node), so every replay starts from zero counters -- 20 replays equal the eager ordinary launch, also after the inputs changed."""
+    ops, probe = forced_persistent
+    q, k, v = _qkv(1, 12, 12, 16384, 16384, 64, BF16, seed=5)
+    sa.sageattn(q, k, v)                                  # warm the allocator outside the capture
+    torch.cuda.synchronize()
+    assert 0 < probe.value < 12 * 128
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out = sa.sageattn(q, k, v)
+    monkeypatch.setattr(ops, "_PERSISTENT", False)
+    for rep in range(2):
+        want = sa.sageattn(q, k, v)
+        torch.cuda.synchronize()
+        assert probe.value == 12 * 128
+        for _ in range(10):
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), f"replay differs (inputs version {rep})"
+        q.copy_(torch.roll(q, 7, dims=2)); k.mul_(0.5); v.add_(0.25)          # new inputs in place: the graph reads the same addresses

@@ -90,6 +90,13 @@ def test_split_kv_planner():
     assert plan(1, 8, 128, 4096, False, 8) == 8                # forced
     with pytest.raises(ValueError):
         plan(1, 8, 128, 4096, False, 7)                        # does not divide the 64 key tiles
+    # FP8 PV (auto_default=False): no split unless asked for -- the default FP8 route has ONE schedule, the one its parity gate names
+    assert plan(1, 32, 128, 32768, False, None, auto_default=False) == 0
+    assert plan(1, 32, 128, 32768, False, "auto", auto_default=False) == 16
+    assert plan(1, 32, 128, 32768, False, 8, auto_default=False) == 8
+    assert plan(1, 32, 128, 32768, False, "auto") == 16
+    with pytest.raises(ValueError):
+        plan(1, 8, 128, 4096, False, "yes")
 
 
 def test_bench_rank_units_partition_the_global_problem():

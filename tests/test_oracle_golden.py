@@ -113,3 +113,43 @@ def test_two_level_equals_single_level_to_rounding(oracle_mod):
                                c=aux["c"], pv_mode=mode, out_dtype=0, v_scale=aux["vs"])
         outs.append(util.f32(o, 0))
     assert np.abs(outs[0] - outs[1]).max() <= 2 ** -10
+
+
+@pytest.mark.parametrize("case", [(1, 4, 2, 300, 300, 128, 0, True, 1.0, "per_thread"), (1, 2, 2, 512, 512, 64, 0, False, 0.0, "per_thread"),
+                                  (1, 2, 1, 1000, 1000, 128, 1, True, 5.0, "per_thread"), (2, 2, 2, 200, 333, 64, 1, False, 2.0, "per_warp"),
+                                  (1, 2, 2, 130, 1100, 128, 0, False, 1.0, "per_block")],
+                         ids=["n300_d128_causal", "n512_d64", "n1000_d128_biased_k_bf16", "cross_d64_per_warp", "long_kv_per_block"])
+def test_folded_scores_vs_exact(oracle_mod, case):
+    """The oracle's two FP8 score forms on the CPU.  `exact` is the reference's formula exp2(fma(s, c, -m)) (attn_utils.cuh:445-449) and
+    stays the pinned mode; `folded` is its reassociation exp2(fma(bits, c', -(m + bias c'))) as the gfx950 kernels' default FP8 loops
+    evaluate it.  Clause (ii) of the rule for a default FP8 schedule variant: rel-RMS <= 1e-2 between the two; clause
+    (iii): accuracy against fp32 SDPA within 1e-4 (cos) / 1e-3 (rel-RMSE) of the exact form's.  The forms are NOT equal: single outputs of
+    rows of a few hundred keys differ by up to ~1.5e-2 * max|o| (an e4m3 rounding of a large P flips), which is why each form has its own
+    2e-3 gate instead of one gate for both."""
+    B, Hq, Hkv, Lq, Lk, D, dt, causal, kbias, gran = case
+    g = torch.Generator().manual_seed(40 + Lq)
+    T = torch.float16 if dt == 0 else torch.bfloat16
+    q = torch.randn(B, Hq, Lq, D, generator=g).to(T)
+    k = (torch.randn(B, Hkv, Lk, D, generator=g) + kbias * torch.randn(1, Hkv, 1, D, generator=g)).to(T)
+    v = torch.randn(B, Hkv, Lk, D, generator=g).to(T)
+    outs = {}
+    for form in ("exact", "folded"):
+        for single in (False, True):
+            o, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8", qk_quant_gran=gran,
+                                                fp8_scores=form, single_level=single)
+            outs[form, single] = util.f32(o, dt)
+    truth = util.sdpa_f32(q, k, v, causal).numpy()
+    tn = float(np.sqrt((truth ** 2).mean()))
+    for single in (False, True):
+        a, b = outs["folded", single], outs["exact", single]
+        assert not np.array_equal(a, b) or Lk <= 64
+        rel_rms = float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+        assert rel_rms <= 1e-2, rel_rms
+        assert np.abs(a - b).max() <= 4e-2 * np.abs(b).max()
+        assert abs(util.cos_sim(a, truth) - util.cos_sim(b, truth)) <= 1e-4
+        assert abs(util.rmse(a, truth) - util.rmse(b, truth)) / tn <= 1e-3
+    # the folded form exists for the FP8 modes only
+    _, _, aux = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16", qk_quant_gran=gran)
+    with pytest.raises(AssertionError):
+        oracle_mod.attn(aux["q8"], aux["k8"], util.bits(v.half()), aux["qs"], aux["gq"], aux["ks"], aux["gk"], causal=causal, c=aux["c"],
+                        pv_mode=oracle_mod.PV_F16_F32ACC, out_dtype=dt, score_mode=oracle_mod.SCORES_FOLDED)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase times of ONE attention launch, from the 100 MHz stamps of a -DSAGE_ATTN_TRACE=1 build of sage_attn.hip
-(tools/build_variants.sh atrace:"-DSAGE_ATTN_TRACE=1"; run with SAGE_GFX950_LIB=variants/libsage_gfx950_atrace.so).
+"""Per-workgroup phase times of ONE attention launch, from the 100 MHz stamps of a -DSAGE_ATTN_TRACE=1 build of the attention units
+(tools/build_variants.sh atrace:"-DSAGE_ATTN_TRACE=1"; run with SAGE_GFX950_LIB=variants/libsage_gfx950_atrace.so).  The stamps land in a
+caller-owned buffer handed over as a launch attribute (SageLaunchAttr.trace; an ordinary build ignores it and the tool sees only zeros).
 usage: attn_trace.py [c3|c2|c5|n1k|n2k|n4k|c4|c4nc]"""
 import ctypes
 import os
@@ -12,14 +13,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from sageattention_amd import _cabi, core
+from sageattention_amd import _cabi, core, ops as sa_ops
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 dev = torch.device("cuda:0")
 lib = _cabi.load()
-if not hasattr(lib, "sage_debug_attn_trace"):
-    sys.exit("this library has no trace: build it with -DSAGE_ATTN_TRACE=1 and point SAGE_GFX950_LIB at it")
-lib.sage_debug_attn_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 if name in ("c4", "c4nc"):
     g = torch.Generator(device="cpu").manual_seed(4)
     total = sum(bench.C4_LENS)
@@ -37,12 +35,14 @@ else:
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-assert lib.sage_debug_attn_trace(None, 0, 1) == 0
+NW = 1 << 15
+sa_ops.trace_buf = torch.zeros(16 * NW, dtype=torch.int32, device=dev)
 step()
 torch.cuda.synchronize()
-NW = 1 << 15
-buf = np.zeros(16 * NW, dtype=np.uint32)
-assert lib.sage_debug_attn_trace(buf.ctypes.data, buf.size, 0) == 0
+buf = sa_ops.trace_buf.cpu().numpy().view(np.uint32)
+sa_ops.trace_buf = None
+if not buf.any():
+    sys.exit("this library has no trace: build it with -DSAGE_ATTN_TRACE=1 and point SAGE_GFX950_LIB at it")
 t = buf.reshape(NW, 16)
 t = t[t[:, 7] != 0]                                   # workgroups that ran to the end (the ones that exit early leave zeros)
 st_ = t[:, :8].astype(np.int64)

@@ -8,12 +8,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import ctypes
+
 import bench
 from sageattention_amd import _cabi, ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda:0")
 lib = _cabi.load()
+ops.grid_probe = probe = ctypes.c_int32(-1)
 cases = [("c3 shape, non-causal, N=%d" % n, dict(bench.CONFIGS["c3nc"], N=n)) for n in (8192, 16384, 32768)] + [("c5", bench.CONFIGS["c5"])]
 for name, cfg in cases:
     q, k, v = bench.make_inputs(cfg, dev, 7)
@@ -27,7 +30,7 @@ for name, cfg in cases:
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
-            grid[on] = int(lib.sage_debug_last_attn_grid())
+            grid[on] = int(probe.value)
             for _ in range(reps // 2):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); step(); b.record(); b.synchronize()

@@ -29,7 +29,7 @@ for name, B, Hq, Hkv, Lq, Lk, D, causal in SHAPES:
     q = torch.randn(B, Hq, Lq, D, device=dev, dtype=torch.bfloat16)
     k = torch.randn(B, Hkv, Lk, D, device=dev, dtype=torch.bfloat16)
     v = torch.randn(B, Hkv, Lk, D, device=dev, dtype=torch.bfloat16)
-    fn = (lambda: sa.sageattn(q, k, v, is_causal=causal, split_kv=0)) if "split off" in name else (lambda: sa.sageattn(q, k, v, is_causal=causal))
+    fn = (lambda: sa.sageattn(q, k, v, is_causal=causal, split_kv=0)) if "split off" in name else (lambda: sa.sageattn(q, k, v, is_causal=causal, split_kv="auto"))
     t_end = time.perf_counter() + 0.2
     while time.perf_counter() < t_end:
         fn()
