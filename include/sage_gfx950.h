@@ -124,12 +124,16 @@ SAGE_API int sage_quant_qk_int8(const void *x, const void *mean, int8_t *out, fl
  *               of slabs, max Lk, sum Lk, 0
  * Results of the attention launch do not depend on either order.  nseq <= sage_varlen_plan_max_seqs(); work_items needs blkq = 128, blkk = 64.
  * Replaces: the torch prefix sums of quant_per_block_varlen.py:68-73 and the `.item()` synchronisations of :75-76; the reference launches
- * ceil(max_seqlen_q / 128) blocks for EVERY sequence and lets the ones past a sequence's end exit (attn_qk_int8_block_varlen.py:98-121). */
+ * ceil(max_seqlen_q / 128) blocks for EVERY sequence and lets the ones past a sequence's end exit (attn_qk_int8_block_varlen.py:98-121).
+ * work_items_cap / slab_seq_cap: the number of (sequence, block) pairs work_items holds and of entries slab_seq holds.  The counts the kernel
+ * derives from cu_seqlens on the device are clamped to them (hdr reports the clamped counts): a cu_seqlens that is inconsistent with the
+ * row counts the buffers were sized from drops work, it never makes this launch or a launch that reads hdr write or read out of bounds. */
 SAGE_API int sage_varlen_plan_max_seqs(void);
 SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int total_k, int blkq, int blkk,
                               int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
                               int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
-                              int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream);
+                              int32_t *work_items, int work_items_cap, int32_t *slab_first, int32_t *slab_seq, int slab_seq_cap,
+                              int32_t *hdr, void *stream);
 /* Host-side view of that work list (the same functions of csrc/sage_work_order.h, run on the host; no GPU needed): lq / lk are HOST arrays of
  * the nseq sequence lengths; items_out receives (sequence, query block) pairs, hdr_out {count, group, fold, left}; returns the grid size of
  * the attention launch or a negative status. */
@@ -190,9 +194,12 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  * Either of k / v may be NULL to run one half.  Results are bit-identical to the sage_channel_mean +
  * sage_quant_qk_int8 + sage_prep_v_fp8 sequence (6 launches, 4 B/elt read): same per-slab summation order.
  *   ws    sage_prepass_ws_floats(B,H,L,D) floats of scratch
- *   sync  sage_prepass_sync_words(B,H) uint32 of scratch, private to the call while it runs (it need not be initialised: the
- *         entry point zeroes it on `stream` before the launch).  Layout: 32 words per (K|V, b, h):
- *         [0] arrivals, [1] departures, [2] give-up flag: set if a workgroup waited tens of milliseconds for the other slabs of its
+ *   sync  sage_prepass_sync_words(B,H) uint32, private to the call while it runs, ZERO ON ENTRY.  The kernel returns the counters it
+ *         used to zero before it ends (also when a workgroup gave up), so a buffer that its owner zeroed once serves every later call
+ *         issued in stream order -- ABI 18 zeroed it with a launch of its own in front of every call (4.8 us and a kernel boundary);
+ *         two launches that may run concurrently need two buffers.  Layout: 32 words per (K|V, b, h):
+ *         [0] arrivals, [1] departures, [2] give-up flag (sticky: the one word the kernel never clears): set if a workgroup waited
+ *         30 ms of wall-clock time for the other slabs of its
  *         head in vain (the co-residency assumption below was violated).  Such a workgroup computes the head's statistics itself --
  *         it re-reads the whole head, slab by slab, through the same summation order -- so the outputs are the same bits as ever; the
  *         launch is slow, not wrong (rounds 2-3 wrote NaN instead).  sage_prepass_failed_heads(sync, B, H, stream) synchronises the

@@ -235,8 +235,11 @@ SAGE_API int sage_varlen_plan_max_seqs(void) { return sage::kVarlenPlanMaxSeq; }
 SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k, int nseq, int total_k, int blkq, int blkk,
                               int is_causal, int Hq, int Hkv, int head_dim, int pv_fp8,
                               int32_t *cu_q_scale, int32_t *cu_k_scale, int32_t *seq_order,
-                              int32_t *work_items, int32_t *slab_first, int32_t *slab_seq, int32_t *hdr, void *stream)
+                              int32_t *work_items, int work_items_cap, int32_t *slab_first, int32_t *slab_seq, int slab_seq_cap,
+                              int32_t *hdr, void *stream)
 {
+    SAGE_REQUIRE((work_items == nullptr || work_items_cap > 0) && (slab_seq == nullptr || slab_seq_cap > 0),
+                 "work_items / slab_seq come with their capacities (got %d, %d)", work_items_cap, slab_seq_cap);
     SAGE_REQUIRE(cu_seqlens_q && cu_seqlens_k && cu_k_scale, "null tensor pointer");
     SAGE_REQUIRE(nseq > 0 && nseq <= sage::kVarlenPlanMaxSeq, "nseq must be in 1 .. %d (got %d)", sage::kVarlenPlanMaxSeq, nseq);
     SAGE_REQUIRE(blkq > 0 && blkk > 0, "block sizes must be positive");
@@ -251,6 +254,7 @@ SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seq
     p.causal = is_causal ? 1 : 0; p.Hq = Hq > 0 ? Hq : 1; p.Hkv = Hkv > 0 ? Hkv : 1; p.head_dim = head_dim; p.pv_fp8 = pv_fp8 ? 1 : 0;
     p.cu_qs = cu_q_scale; p.cu_ks = cu_k_scale; p.order = seq_order; p.items = work_items;
     p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
+    p.items_cap = work_items_cap; p.slab_cap = slab_seq_cap;
     return check_launch(sage::launch_varlen_plan(p, static_cast<hipStream_t>(stream)), "sage_varlen_plan launch");
 }
 // host-side view of the work list (csrc/sage_work_order.h, the functions varlen_plan_kernel runs; no GPU needed): lq / lk are HOST arrays of

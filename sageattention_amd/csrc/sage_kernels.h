@@ -112,6 +112,8 @@ struct VarlenPlanParams {
                                          // (index nseq: rows cu_k[nseq] .. total_k, index nseq + 1: rows 0 .. cu_k[0]) that only the K mean reads
     int32_t *slab_seq;                   // nullable [nslab]: slab -> segment (sequence, or nseq / nseq + 1 for the gaps)
     int32_t *hdr;                        // nullable [kVarlenHdrWords]
+    int items_cap, slab_cap;             // (sequence, query block) pairs `items` holds, entries of `slab_seq`: counts derived from cu_seqlens on the
+                                         // device are clamped to them (hdr reports the clamped counts), so an inconsistent cu_seqlens cannot write past
 };
 hipError_t launch_varlen_plan(const VarlenPlanParams &p, hipStream_t stream);
 
@@ -166,8 +168,8 @@ struct PrepassParams {
     float *v_scale;           // [B,H,D] out
     float *v_mean;            // nullable [B,H,D] out; non-null = smooth_v
     float *ws;                // [2,B,H,nslab,3,D] slab partials
-    unsigned *sync;           // [2,B,H,kPrepassSyncStride] per head: arrival counter, departure counter, give-up flag; zeroed by the
-                              // launcher (a small kernel on the launch stream) before every launch
+    unsigned *sync;           // [2,B,H,kPrepassSyncStride] per head: arrival counter, departure counter, give-up flag.  ZERO on entry (the
+                              // caller zeroes the buffer once); the kernel returns both counters to zero before it ends
     int B, H, L, D, nslab;
     long k_sb, k_sh, k_sl;
     long v_sb, v_sh, v_sl;

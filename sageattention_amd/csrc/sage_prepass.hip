@@ -18,9 +18,10 @@
 // capacity (2 per CU).
 // The same assumption carries rocPRIM's decoupled look-back scan.  Cross-XCD visibility of the partials follows the
 // gfx942+ memory model for atomics: the arrival counter and the partials are agent-scope atomic accesses.
-// The two counters of a head return to zero before the kernel ends, so one zero-initialised sync buffer serves every
-// call issued in stream order (the C ABI zeroes the buffer before every launch all the same).  The wait is bounded (tens of
-// milliseconds) and the assumption is not load-bearing for correctness: a workgroup whose head-mates have not all arrived in time sets
+// The two counters of a head return to zero before the kernel ends -- the last slab to leave re-arms them, also in a launch in which a
+// workgroup gave up -- so ONE buffer that its owner zeroed ONCE serves every call issued in stream order: there is no zeroing launch in
+// front of the kernel any more (round 5: that launch was 4.8 us plus a kernel boundary of every sageattn() call).  The wait is bounded
+// (30 ms of the 100 MHz wall clock) and the assumption is not load-bearing for correctness: a workgroup whose head-mates have not all arrived in time sets
 // word 2 of the head's sync line (and the caller's pinned host word), then computes the head's statistics ITSELF -- it streams the whole
 // head through a rolled copy of the statistics pass, slab by slab in index order, which reproduces every slab's partial bit for bit --
 // and carries on.  The launch is then slow (nslab x the read traffic for that workgroup), never wrong: rounds 2-3 poisoned the outputs
@@ -276,11 +277,14 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 // stream's kernels -- this workgroup stops waiting, records it (word 2 of the head's sync line, the caller's host word) and
                 // computes the head's statistics ITSELF below; nothing it writes depends on another workgroup then
                 const unsigned want = (unsigned)nslab + (p.debug_fail ? 1u : 0u);
-                const unsigned bound = p.debug_fail ? (1u << 10) : (1u << 15);
-                unsigned polls = 0, gave_up = 0;
+                // a TIME bound (the 100 MHz wall clock: 30 ms; the test hook 0.2 ms), not a poll count: how long a poll takes depends on how
+                // contended the coherence point is, and the bound is what separates "a slow head-mate" from "a head-mate that is not running"
+                const long long bound = p.debug_fail ? 20000LL : 3000000LL;
+                const long long t0 = wall_clock64();
+                unsigned gave_up = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++polls > bound) {
+                    if (wall_clock64() - t0 > bound) {
                         __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (p.host_flag != nullptr) __hip_atomic_store(p.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         gave_up = 1;
@@ -710,12 +714,6 @@ prepass_kv_kernel(const PrepassParams p)
     } else prepass_body<D, DT, false, VARLEN>(p, lds, b);
 }
 
-__global__ void __launch_bounds__(256) prepass_zero_sync_kernel(unsigned *sync, int words)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < words) sync[i] = 0u;
-}
-
 __global__ void __launch_bounds__(1024) debug_spin_kernel(long long ticks)
 {
     const long long t0 = wall_clock64();                // 100 MHz
@@ -731,10 +729,6 @@ hipError_t launch_debug_spin(int ms, int nwg, hipStream_t s)
 hipError_t launch_prepass_kv(const PrepassParams &p, hipStream_t s)
 {
     if (p.B <= 0 || p.H <= 0 || p.nslab <= 0 || p.parts == 0) return hipSuccess;
-    {
-        const int words = 2 * p.B * p.H * kPrepassSyncStride;
-        hipLaunchKernelGGL(prepass_zero_sync_kernel, dim3((words + 255) / 256), dim3(256), 0, s, p.sync, words);
-    }
     dim3 grid(p.nslab, p.H, p.B * (p.parts == 3 ? 2 : 1));
 #define SAGE_PP(D_, T_) do { if (p.cu != nullptr) hipLaunchKernelGGL((prepass_kv_kernel<D_, T_, true>), grid, dim3(kPrepassThreads), 0, s, p); \
                              else hipLaunchKernelGGL((prepass_kv_kernel<D_, T_, false>), grid, dim3(kPrepassThreads), 0, s, p); } while (0)

@@ -60,7 +60,12 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
     const int nslab_seq = ss[cur][nseq - 1];
     const int tail = max(p.total_k - p.cu_k[nseq], 0), head = max(p.cu_k[0], 0);
     const int nslab_tail = (tail + kStatsSlab - 1) / kStatsSlab, nslab_head = (head + kStatsSlab - 1) / kStatsSlab;
-    const int nitems = sq[cur][nseq - 1], nslab = nslab_seq + nslab_tail + nslab_head;
+    // the counts come from cu_seqlens on the device, the buffers were sized on the host from q.shape[0] / k.shape[0]: a cu_seqlens that is
+    // inconsistent with them (last prefix beyond the rows, not monotonic) must not make this kernel -- or the launches that read hdr -- run
+    // past the allocations.  Clamped counts drop work (the call's result is then as undefined as its input), they never write out of bounds.
+    const int nitems_all = sq[cur][nseq - 1], nslab_all = nslab_seq + nslab_tail + nslab_head;
+    const int nitems = p.items != nullptr ? min(nitems_all, p.items_cap) : nitems_all;
+    const int nslab = p.slab_seq != nullptr ? min(nslab_all, p.slab_cap) : nslab_all;
     if (i == 0) {
         if (p.cu_qs != nullptr) p.cu_qs[0] = 0;
         p.cu_ks[0] = 0;
@@ -69,7 +74,7 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
             WorkOrder w;
             plan_varlen_order(w, p.Hq, p.Hq / p.Hkv, nitems, (long)max_lk, p.head_dim, p.pv_fp8 != 0);
             p.hdr[0] = nitems; p.hdr[1] = w.group; p.hdr[2] = w.fold; p.hdr[3] = w.left;
-            p.hdr[4] = nslab; p.hdr[5] = max_lk; p.hdr[6] = p.cu_k[nseq] - p.cu_k[0]; p.hdr[7] = nslab - nslab_seq;
+            p.hdr[4] = nslab; p.hdr[5] = max_lk; p.hdr[6] = p.cu_k[nseq] - p.cu_k[0]; p.hdr[7] = max(nslab - nslab_seq, 0);
         }
     }
     // inclusive scan value of sequence t = number of blocks / slabs in sequences 0 .. t: the first t with scan[t] > idx owns index idx
@@ -82,12 +87,14 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
         return lo;
     };
     if (p.items != nullptr && p.blkq == BLKQ && p.blkk == BLKK) {
-        for (int idx = i; idx < nitems; idx += 1024) {
+        for (int idx = i; idx < nitems_all; idx += 1024) {
             const int s = owner(sq[cur], idx);
             const int j = idx - (s > 0 ? sq[cur][s - 1] : 0);
             const int rank = varlen_item_rank(lq_s, lk_s, nseq, s, j, p.causal != 0);
-            p.items[2 * rank] = s;
-            p.items[2 * rank + 1] = j;
+            if (rank >= 0 && rank < nitems) {
+                p.items[2 * rank] = s;
+                p.items[2 * rank + 1] = j;
+            }
         }
     }
     if (p.slab_seq != nullptr) {

@@ -182,7 +182,7 @@ def varlen_plan(cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, BLKQ: in
         slab_first = torch.empty((nseq + 3,), dtype=torch.int32, device=dev)
         slab_seq = torch.empty((slab_bound,), dtype=torch.int32, device=dev)
     rc = lib.sage_varlen_plan(_p(cu_seqlens_q), _p(cu_seqlens_k), nseq, int(total_k) if work else 0, BLKQ, BLKK, int(is_causal), int(Hq), int(Hkv), int(head_dim),
-                              int(pv_fp8), _p(cu_qs), _p(cu_ks), _p(order), _p(items), _p(slab_first), _p(slab_seq), _p(hdr),
+                              int(pv_fp8), _p(cu_qs), _p(cu_ks), _p(order), _p(items), items_bound, _p(slab_first), _p(slab_seq), slab_bound, _p(hdr),
                               _stream(cu_seqlens_q))
     _cabi.check(rc, "sage_varlen_plan")
     return VarlenPlan(cu_qs, cu_ks, order, items, hdr, slab_first, slab_seq, items_bound, slab_bound)
@@ -301,10 +301,24 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     return v_image, v_scale, vm
 
 
+_SYNC_CACHE: dict = {}      # (device index, stream handle) -> zeroed int32 tensor
+
+
 def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
-    """Scratch for the per-head counters of the fused pre-pass: a fresh, uninitialised buffer per call (the C ABI zeroes it on
-    the launch stream), so no state survives from one call to the next."""
-    return torch.empty((int(_cabi.load().sage_prepass_sync_words(B, H)),), dtype=torch.int32, device=device)
+    """The per-head counters of the fused pre-pass (``sync`` of ``sage_prepass_kv``): ZERO on entry, and returned to zero by the kernel
+    before it ends, so one buffer per (device, stream), zeroed ONCE when it is created, serves every call issued on that stream -- no
+    zeroing launch per call (round 5; launches on one stream run in order, launches on different streams get different buffers).  The
+    buffer is this module's, not the library's: the C ABI keeps no state.  Inside a graph capture a fresh zeroed buffer is recorded with
+    the capture instead (a captured graph must not depend on memory the cache may replace)."""
+    words = int(_cabi.load().sage_prepass_sync_words(B, H))
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((words,), dtype=torch.int32, device=device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    buf = _SYNC_CACHE.get(key)
+    if buf is None or buf.numel() < words:
+        buf = _SYNC_CACHE[key] = torch.zeros((max(words, 4096),), dtype=torch.int32, device=device)
+    return buf
 
 
 def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
@@ -323,7 +337,8 @@ class _PrepassGuard:
     (an RCCL kernel beside the attention stream).  A workgroup that waits in vain (tens of milliseconds) computes the head's statistics
     itself -- the result is still right, the launch is slow -- and stores 1 into this guard's pinned host word (``host_flag`` of
     ``sage_prepass_kv``).  The word is read -- a plain host memory read, no synchronisation -- at the start of every later pre-pass on the
-    device: once it is set the device's calls take the kernel sequence for the rest of the process (a warning says so once)."""
+    device: once it is set the device's calls take the kernel sequence for ``REARM_SECONDS`` (doubling with every further trip; a warning
+    says so once) -- the stall that tripped it may have been transient -- and then try the one launch again."""
     _by_device: dict = {}
 
     def __init__(self, device: torch.device):
@@ -342,17 +357,29 @@ class _PrepassGuard:
             g = cls._by_device[idx] = cls(torch.device("cuda", idx))
         return g
 
+    REARM_SECONDS = 30.0        # a tripped guard lets the one-launch route try again after this long (a transient stall must not cost the process)
+
     def fused_allowed(self) -> bool:
+        import time
         if not self.tripped and ctypes.c_int32.from_address(self.host).value != 0:
             self.tripped = True
-            warnings.warn(f"sageattention_amd: a one-launch K/V pre-pass on {self.device} stopped waiting for the other slabs of a head "
-                          "(compute units held by another stream?) and recomputed the head's statistics per workgroup: that call was "
-                          "correct but slow.  This device's calls take the kernel sequence from now on.", RuntimeWarning, stacklevel=3)
+            self.tripped_at = time.monotonic()
+            self.trips = getattr(self, "trips", 0) + 1
+            if self.trips == 1:
+                warnings.warn(f"sageattention_amd: a one-launch K/V pre-pass on {self.device} stopped waiting for the other slabs of a head "
+                              "(compute units held by another stream?) and recomputed the head's statistics per workgroup: that call was "
+                              f"correct but slow.  This device's calls take the kernel sequence for the next {self.REARM_SECONDS:.0f} s.",
+                              RuntimeWarning, stacklevel=3)
+        elif self.tripped and time.monotonic() - self.tripped_at > self.REARM_SECONDS * min(2 ** (self.trips - 1), 64):
+            # (every further trip doubles the pause: a device that really cannot hold a head's slabs settles on the kernel sequence)
+            ctypes.c_int32.from_address(self.host).value = 0
+            self.tripped = False
         return not self.tripped
 
     def reset(self) -> None:          # tests
         ctypes.c_int32.from_address(self.host).value = 0
         self.tripped = False
+        self.trips = 0
 
 
 def prepass_fused_ok(k: torch.Tensor, tensor_layout: str = "HND") -> bool:
@@ -379,7 +406,8 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     (quant.py:105-180) -- the K conventions of the reference's CUDA entry points --, "per_block_triton" one scale per BLKK keys with
     the Triton rounding (quant_per_block.py:21-46, the Triton-named API).  ``v_fp16=True`` (FP16-PV entry points) makes
     the V half the fp16 tile image of ``prep_v_fp16`` instead (``v_scale`` and ``vm`` are then None).  ``sync``: optional
-    caller-owned int32 scratch of ``sage_prepass_sync_words(B, H)`` words (to inspect with ``prepass_failed_heads`` afterwards)."""
+    caller-owned int32 buffer of ``sage_prepass_sync_words(B, H)`` words, ZERO on entry (the kernel leaves its counters at zero; to
+    inspect with ``prepass_failed_heads`` afterwards)."""
     k = _aligned(k, 8)
     B, H, L, D, k_sb, k_sh, k_sl = _dims(k, tensor_layout)
     dev = k.device
@@ -420,6 +448,7 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     if _DEBUG:
         n = prepass_failed_heads(sync, B, H)
         if n:
+            sync.zero_()           # (the give-up flags, word 2 of a head's line, are the one thing the kernel does not clear itself)
             warnings.warn(f"sage_prepass_kv: in {n} (K|V, batch, head) entries a workgroup stopped waiting for the other slabs of its head and "
                           "recomputed the statistics itself (slow, not wrong); is the stream restricted to few compute units?", RuntimeWarning)
     return km, k_int8, k_scale, v_image, v_scale, vm
@@ -473,6 +502,7 @@ def prepass_kv_varlen(k: torch.Tensor, v: Optional[torch.Tensor], cu_seqlens_k: 
     if _DEBUG:
         n = prepass_failed_heads(sync, 1, H)
         if n:
+            sync.zero_()
             warnings.warn(f"sage_prepass_kv_varlen: in {n} heads a workgroup stopped waiting for the other slabs and recomputed the statistics "
                           "itself (slow, not wrong)", RuntimeWarning)
     return km, k_int8, k_scale, v_image

@@ -63,10 +63,12 @@ def test_argument_errors_do_not_need_a_gpu():
                                              0, 1.0, 1, 0, None, None)
     assert rc == -1 and b"work list" in lib.sage_last_error()
     # the varlen plan: sequence count, and the work list needs the attention kernel's block sizes
-    rc = lib.sage_varlen_plan(p, p, 5000, 0, 128, 64, 0, 8, 8, 128, 0, None, p, p, None, None, None, None, None)
+    rc = lib.sage_varlen_plan(p, p, 5000, 0, 128, 64, 0, 8, 8, 128, 0, None, p, p, None, 0, None, None, 0, None, None)
     assert rc == -1 and b"nseq" in lib.sage_last_error()
-    rc = lib.sage_varlen_plan(p, p, 4, 0, 64, 64, 0, 8, 8, 128, 0, None, p, p, p, None, None, p, None)
+    rc = lib.sage_varlen_plan(p, p, 4, 0, 64, 64, 0, 8, 8, 128, 0, None, p, p, p, 16, None, None, 0, p, None)
     assert rc == -1 and b"work list" in lib.sage_last_error()
+    rc = lib.sage_varlen_plan(p, p, 4, 100, 128, 64, 0, 8, 8, 128, 0, None, p, p, p, 0, p, p, 8, p, None)       # a work list without its capacity
+    assert rc == -1 and b"capacities" in lib.sage_last_error()
     # the work-order debug view checks every argument (a zero block count used to divide by zero)
     h, r = ctypes.c_int(), ctypes.c_int()
     assert lib.sage_debug_work_item(0, 8, 8, 0, 2, 0, 0, ctypes.byref(h), ctypes.byref(r)) == -1

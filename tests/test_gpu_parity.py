@@ -341,7 +341,7 @@ def test_edge_shapes_vs_oracle(oracle_mod, shape, pv, causal):
     torch.cuda.synchronize()
     km = util.bits(sq.channel_mean(kd))
     ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv=pv,
-                                                qk_quant_gran="per_thread", return_lse=True, km=km)
+                                                qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=SCORES)
     got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
     assert np.isfinite(got).all()
     scale = float(np.abs(ref).max())
@@ -1213,7 +1213,7 @@ def test_varlen_one_launch_prepass_is_bit_identical_to_the_sequence(dt, D, hkv, 
         cu_k = torch.tensor([0] + list(np.cumsum(klens)), dtype=torch.int32, device=DEV)
         plan = sq.varlen_plan(cu_q, cu_k, total_q=sum(lens), total_k=total, Hq=hkv, Hkv=hkv, head_dim=D)
         assert sq.prepass_varlen_fused_ok(k, plan, max(klens), smooth_k)
-        sync = torch.empty(int(sq._cabi.load().sage_prepass_sync_words(1, hkv)), dtype=torch.int32, device=DEV)
+        sync = torch.zeros(int(sq._cabi.load().sage_prepass_sync_words(1, hkv)), dtype=torch.int32, device=DEV)
         km1, k81, ks1, img1 = sq.prepass_kv_varlen(k, v, cu_k, plan, max(klens), smooth_k=smooth_k, sync=sync)
         assert sq.prepass_failed_heads(sync, 1, hkv) == 0
         km0 = sq.channel_mean_packed(k, cu_k, plan) if smooth_k else None

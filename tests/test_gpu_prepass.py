@@ -69,8 +69,8 @@ CASES = [  # B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran
 def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth_k, smooth_v, blkk, gran):
     k, v = _mk(B, H, L, D, dtype, layout, 7 * L + D)
     ref = _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran)
-    sync = torch.full((int(_cabi.load().sage_prepass_sync_words(B, H)),), 0x5a5a5a5a, dtype=torch.int32, device="cuda")   # dirty on purpose
-    for rep in range(3):                   # the same (dirty) sync buffer serves every call: the entry point zeroes it
+    sync = torch.zeros((int(_cabi.load().sage_prepass_sync_words(B, H)),), dtype=torch.int32, device="cuda")   # zeroed ONCE by its owner
+    for rep in range(3):                   # the same buffer serves every call: the kernel returns its counters to zero (no zeroing launch)
         got = quant.prepass_kv_fp8(k, v, layout, smooth_k=smooth_k, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran, sync=sync)
         for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, f"{name} (call {rep})")
@@ -210,7 +210,7 @@ def test_head_barrier_makes_progress_while_other_kernels_hold_the_chip():
     torch.cuda.synchronize()
     s_attn, s_pp = torch.cuda.Stream(), torch.cuda.Stream()
     words = int(_cabi.load().sage_prepass_sync_words(2, 32))
-    syncs = [(torch.empty(words, dtype=torch.int32, device="cuda"), torch.empty(words, dtype=torch.int32, device="cuda")) for _ in range(4)]
+    syncs = [(torch.zeros(words, dtype=torch.int32, device="cuda"), torch.zeros(words, dtype=torch.int32, device="cuda")) for _ in range(4)]
     outs = []
     for rep in range(4):
         with torch.cuda.stream(s_attn):
@@ -242,7 +242,7 @@ def test_a_workgroup_that_gives_up_computes_the_head_itself():
         k, v = _mk(B, H, L, D, dt, "HND", 5 + L)
         want = quant.prepass_kv_fp8(k, v, "HND", smooth_k=True, smooth_v=smooth_v and not v16, qk_quant_gran=gran, v_fp16=v16)
         torch.cuda.synchronize()
-        sync = torch.empty(int(lib.sage_prepass_sync_words(B, H)), dtype=torch.int32, device="cuda")
+        sync = torch.zeros(int(lib.sage_prepass_sync_words(B, H)), dtype=torch.int32, device="cuda")
         guard.reset()
         lib.sage_debug_prepass_fail(1)
         try:
@@ -315,7 +315,7 @@ def test_a_give_up_reroutes_the_device_to_the_kernel_sequence():
             third = sa.sageattn(q, k, v, is_causal=True)
             vl = sa.sageattn_varlen(qv, kv, vv, cu, cu, 800, 800, is_causal=True)
             torch.cuda.synchronize()
-        assert len([x for x in w if "kernel sequence from now on" in str(x.message)]) == 1, [str(x.message) for x in w]
+        assert len([x for x in w if "take the kernel sequence for the next" in str(x.message)]) == 1, [str(x.message) for x in w]
         assert guard.tripped and not quant.prepass_fused_ok(k)
         assert torch.equal(second, want) and torch.equal(third, want) and torch.equal(vl, want_v)
     finally:
