@@ -74,15 +74,27 @@ CONFIGS = {
 # instruction the PV step issues; the non-scaled fp8 MFMA runs at the bf16 rate), int8 = 2x bf16 = 5.0 POPS.
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
-# HBM-side bytes per launch of the attention kernel measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KiB, gfx950 correction per
-# MI355X_MICROARCH.md; FETCH_SIZE counts what the L2s request from the fabric, Infinity-Cache hits included), round 4,
-# profiles/r4_run_j_pmc_traffic.txt: c3 (2 x 147603 + 131072) KiB, c2 (2 x 106764 + 65536) KiB -- the causal work order's groups of heads share an
-# XCD's L2 (round 2's head-major order moved 350.2e6 / 205.2e6 and was 5-15 % slower); c4 causal (2 x 549754 + 268096) KiB, non-causal
-# (2 x 609647 + 268096) KiB: K + V of one kv-head of the 16384-token sequence are 6.3 MB against a 4 MB L2; c5 (non-causal): profiles/r2_run_m_pmc_c5.txt
-PMC_TRAFFIC_BYTES = {"c3": 436.5e6, "c5": 602.4e6, "c2": 285.8e6, "c4": 1400.4e6, "c4nc": 1523.1e6}
-# algorithmic bytes: INT8 q (kernel-only bench) + 16-bit o + INT8 k + FP8 / FP16 V image; c4: 16-bit q (quantised in the prologue) + o + k + fp16 V
-ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6, "c4": 651.9e6, "c4nc": 651.9e6}
-PMC_NOTE = "L2-miss bytes per launch from committed rocprofv3 PMC passes (profiles/r4_run_j_pmc_traffic.txt, r2_run_m_pmc_c5.txt)"
+# HBM-side bytes per launch of the dominant kernels: read from profiles/r5_pmc.json, the summary tools/pmc_collect.py wrote from rocprofv3 --pmc
+# passes at the commit named inside it ((2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB; FETCH_SIZE and WRITE_SIZE in passes of their own; the gfx950
+# correction per MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide streaming reads).  One entry per driver-run configuration;
+# profiles/r5_pmc_<cfg>.txt holds the raw counters and the other derived figures (VALU-active, MFMA-busy, waves per SIMD, LDS conflicts).
+# algorithmic bytes: INT8 q (kernel-only bench) + 16-bit o + INT8 k + FP8 / FP16 V image; c4 / c2t: 16-bit q (quantised in the prologue)
+ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6, "c4": 651.9e6, "c4nc": 651.9e6, "c2t": 268.4e6}
+_PMC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_pmc.json")
+try:
+    PMC = json.load(open(_PMC_PATH))
+except Exception:          # (a checkout without the profile: traffic is reported as null, never as a stale constant)
+    PMC = {}
+
+
+def pmc_traffic(config_name):
+    """(bytes per launch | None, note) for a bench configuration from the committed PMC summary."""
+    e = PMC.get(config_name)
+    if not e:
+        return None, None
+    return float(e["traffic_bytes"]), ("rocprofv3 --pmc passes at commit %s, %s: (2 x FETCH_SIZE %.0f + WRITE_SIZE %.0f) KiB; algorithmic %.4g B (x %.2f)"
+                                       % (e.get("commit", "?"), e.get("file", "profiles/r5_pmc.json"), e["fetch_kib"], e["write_kib"],
+                                          e["algorithmic_bytes"], e["traffic_over_algorithmic"]))
 
 
 def blended_peak(pv: str) -> float:
@@ -233,8 +245,8 @@ def prepass_roofline(cfg, k, v, config_name, between=None):
     nbytes = 2 * 3 * k.numel()
     return {"kernel": "prepass_kv_kernel", "bound": "hbm", "avg_launch_ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "algorithmic_bytes": nbytes,
-            "traffic": 405.0e6 if config_name == "c3" else None,
-            "traffic_note": "PMC passes, profiles/r2_run_r3j_pmc_prepass_c3.txt" if config_name == "c3" else None,
+            "traffic": pmc_traffic("pp")[0] if config_name == "c3" else None,
+            "traffic_note": pmc_traffic("pp")[1] if config_name == "c3" else None,
             "how": "HIP events around each launch, the workload's attention kernel launched in between (cold Infinity Cache, as inside sageattn())"}
 
 
@@ -285,8 +297,8 @@ def roofline_obj(fl, kern_ms, pv, kernel, config_name=None):
     achieved = fl / (kern_ms * 1e-3) / 1e12
     peak = blended_peak(pv)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": PMC_TRAFFIC_BYTES.get(config_name),
-            "traffic_note": (PMC_NOTE + ", algorithmic %.4g" % ALGO_BYTES[config_name]) if config_name in PMC_TRAFFIC_BYTES else None,
+            "traffic": pmc_traffic(config_name)[0],
+            "traffic_note": pmc_traffic(config_name)[1],
             "kernel": kernel, "avg_launch_ms": round(kern_ms, 4), "algorithmic_flops_per_launch": fl, "peak_note": peak_note(pv),
             "how": "HIP events around every launch on the launch stream, average of the timed launches"}
 
@@ -421,7 +433,7 @@ def measure_triton_api(cfg, q, k, v, steps, warmup, ramp):
     wall, _ = timed(lambda: sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, is_causal=cfg["causal"]), n, 2, False, ramp)
     return {"workload": "sageattn_qk_int8_pv_fp16_triton at the C2 shape (B=2 H=32 N=4096 D=128 causal, fp16)",
             "kernel_only": {"ms_per_launch": round(kern_ms, 4), "tflops": round(fl / kern_ms / 1e9, 2)},
-            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (per-block Q quantised in the prologue, Triton kernel form)"),
+            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (per-block Q quantised in the prologue, Triton kernel form)", "c2t"),
             "end_to_end": {"ms_per_call": round(wall / n * 1e3, 4), "tflops": round(fl / (wall / n) / 1e12, 2)}}
 
 
@@ -637,6 +649,7 @@ def main():
         "vs_baseline": round(value / world / 795.0, 4) if args.config == "c3" else None,
         "vs_baseline_note": "per-GPU kernel-only TFLOPS / 795 (SageAttn2-8b, H100, hd128 causal N=8k; BASELINE.md section 1)",
         "dtype": "int8 QK^T + " + ("fp8(e4m3) PV" if cfg["pv"] == "fp8" else "fp16 PV") + ", fp32 accumulate",
+        "fp8_score_form": (("exact" if __import__("sageattention_amd.ops", fromlist=["_FP8_EXACT"])._FP8_EXACT else "folded") if cfg["pv"] == "fp8" else None),
         "data": "synthetic (randn, quantised by the product's own pre-pass kernels)",
         "config": {"workload": cfg["workload"], "global_batch": cfg["B_global"] * world, "heads": CONFIGS[args.config]["H"], "seq_len": cfg["N"],
                    "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world} (shard.shard_range units of the global batch), no collective"},
@@ -671,6 +684,30 @@ def main():
                     sweep[str(n)] = round(flops(c) / (_median(d) * 1e-3) / 1e12, 1)
                     del qq, kk, vv, oo
                 out[key] = sweep
+            # the reference's bench helper writes 256 MB between repetitions so that no launch finds its operands in a cache
+            # (bench/utils.py:7-33); MI355X has a 256 MB Infinity Cache, which holds the operands of every sweep point up to N = 4k
+            flush = torch.empty(int(256e6) // 4, dtype=torch.int32, device=device)
+            cold = {}
+            for n in (1024, 2048, 4096, 8192, 16384, 32768):
+                c = dict(CONFIGS[args.config], N=n, B=cfg["B_global"])
+                qq, kk, vv = make_inputs(c, device, 99)
+                oo = prequantize(c, qq, kk, vv)
+                timed(lambda: kernel_only_step(c, oo, sm_scale), 5, 5, False, min(args.ramp_seconds, 0.2))
+                d = []
+                for _ in range(12):
+                    flush.zero_()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    kernel_only_step(c, oo, sm_scale)
+                    b.record()
+                    b.synchronize()
+                    d.append(a.elapsed_time(b))
+                cold[str(n)] = round(flops(c) / (_median(d) * 1e-3) / 1e12, 1)
+                del qq, kk, vv, oo
+            del flush
+            out["sweep_kernel_only_tflops_cache_flushed"] = cold
+            out["sweep_flushed_note"] = ("the same sweep with 256 MB written between launches (the reference's bench/utils.py:7-33 flush; MI355X's Infinity "
+                                         "Cache is 256 MB): median of 12 single launches each, every launch timed on its own behind the flush")
             out["sweep_note"] = ("kernel-only TFLOP/s of the workload's kernel at N = 1k .. 32k (B=%d, H=%d, D=%d, %s): median of 20 launches each, HIP events"
                                  % (cfg["B_global"], CONFIGS[args.config]["H"], cfg["D"], "causal" if cfg["causal"] else "non-causal"))
         if args.config == "c3" and world == 1 and not args.no_configs:

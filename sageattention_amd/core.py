@@ -401,8 +401,9 @@ def _varlen_attend(st: _VarlenState) -> torch.Tensor:
     plan = st.plan
     items, hdr, bound = (plan.items, plan.hdr, plan.items_bound) if plan is not None else (None, None, 0)
     nseq = st.cu_q.shape[0] - 1
-    # (a large non-causal call runs as a persistent launch; items = 128-row blocks of the packed rows, at least)
-    attr = ops.attn_attr(q.device, st.is_causal, Hq * (q.shape[0] // 128)) if plan is not None else None
+    # (a large call over the work list runs as a persistent launch -- causal too, on the fused-Q route whose causal kernels carry the ticket
+    #  loop; items = 128-row blocks of the packed rows, at least)
+    attr = ops.attn_attr(q.device, st.is_causal, Hq * (q.shape[0] // 128), packed=st.fuse_q) if plan is not None else None
     if st.fuse_q:
         rc = _cabi.load().sage_attn_fused_qblock_pv_f16_varlen(
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_ks), _p(st.order),

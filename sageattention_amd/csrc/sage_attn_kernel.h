@@ -93,6 +93,9 @@
                         // pipelined or not, so the oracle's `score_mode = folded` mirrors it rounding for rounding (oracle/sage_oracle.c) and
                         // the 2e-3 * max|o| gate is kept against that mode; SAGE_ATTR_FP8_EXACT_SCORES selects the exact form of rounds 1-4,
                         // which stays the one pinned to the reference's formula exp2(fma(s, c, -m)) (attn_utils.cuh:445-449).
+#ifndef SAGE_PERS_QF      // 0: A/B build without the ticket loop in the causal kernels of the packed route (QF 3 / 4)
+#define SAGE_PERS_QF 1
+#endif
 #ifndef SAGE_PERS_CAUSAL  // experiment (tools/pers_causal_probe.py): the persistent ticket loop compiled into the causal instantiations as well
 #define SAGE_PERS_CAUSAL 0
 #endif
@@ -208,7 +211,10 @@ sage_attn_kernel(const AttnParams p_arg)
     //      address serialise at ~200 ns each, and the 64 workgroups of an XCD finish equal items together.
     //      Causal launches keep the hardware's dispatch: their work order pairs a long and a short block on a CU through the order in which
     //      freed slots are refilled, and tickets lose that (measured: +2.6 % at C3, +7 % at C2).
-    constexpr bool PERS_OK = (!CAUSAL || SAGE_PERS_CAUSAL != 0) && MASK == 0;
+    // (round 5: the loop is also in the causal kernels of the packed / varlen route -- QF 3 / 4, per-block Q quantised in the prologue --, whose
+    //  launches over the device-built work list gain 2.9 % from it at C4; dense causal launches lose 0.1 ... 7.5 % and never take it:
+    //  profiles/r5_pers_causal_probe.txt)
+    constexpr bool PERS_OK = (!CAUSAL || (QF >= 3 && SAGE_PERS_QF != 0) || SAGE_PERS_CAUSAL != 0) && MASK == 0;
     const bool pers = PERS_OK && p.sched != nullptr;
     __shared__ int s_ticket[2];                 // (two slots, alternating: a wave may still be reading the previous ticket when wave 0 posts the next)
     int tpar = 0;
@@ -1726,7 +1732,9 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
     static_assert(PV_FP8 || SFOLD, "FP16 PV has one score form");
     constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
     using C = TileCfg<D, PV_FP8, NH>;
-    const bool pers = !v.causal || SAGE_PERS_CAUSAL != 0;
+    // causal launches take the ticket route only over a packed batch's work list (items of very different lengths, heaviest first: +2.9 % at
+    // C4); dense causal launches keep the hardware's dispatch, which their work order is built on (-0.1 ... -7.5 % with tickets)
+    const bool pers = !v.causal || SAGE_PERS_CAUSAL != 0 || (SAGE_PERS_QF != 0 && v.qf >= 3 && p.cu_q != nullptr && p.work_items != nullptr);
     if (v.mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, tile product folded into the FP32 output
         if constexpr (!PV_FP8) {
             using CM = TileCfg<D, false, 1>;

@@ -51,12 +51,13 @@ def fp8_exact(kwarg=None) -> bool:
     return kwarg == "exact"
 
 
-def attn_launch_ws(device: torch.device, is_causal, n_items: int) -> Optional[torch.Tensor]:
+def attn_launch_ws(device: torch.device, is_causal, n_items: int, packed: bool = False) -> Optional[torch.Tensor]:
     """The launch workspace of an attention launch (``SageLaunchAttr.launch_ws``, include/sage_gfx950.h): a zeroed counter block that lets a
-    large NON-CAUSAL launch run as a persistent launch over ticket queues (2.2-2.8 % faster on the CogVideoX shape and on packed batches;
-    results do not depend on it).  Returns the tensor or None.  ``n_items``: 128-row query blocks x heads x batch of the call.  A
-    performance attribute only: SAGE_PERSISTENT_LAUNCH=0 switches it off."""
-    if is_causal or not _PERSISTENT or n_items < _PERSISTENT_MIN_ITEMS:
+    large launch run as a persistent launch over ticket queues -- NON-CAUSAL launches (2.2-2.8 % faster on the CogVideoX shape and on
+    packed batches) and, ``packed``, the causal launch of ``sageattn_varlen`` over its work list (+2.9 % at C4); dense causal launches
+    keep the hardware's dispatch.  Results do not depend on it.  Returns the tensor or None.  ``n_items``: 128-row query blocks x heads
+    x batch of the call.  A performance attribute only: SAGE_PERSISTENT_LAUNCH=0 switches it off."""
+    if (is_causal and not packed) or not _PERSISTENT or n_items < _PERSISTENT_MIN_ITEMS:
         return None
     return torch.zeros((int(_cabi.load().sage_attn_launch_ws_bytes()) // 4,), dtype=torch.int32, device=device)
 
@@ -69,11 +70,11 @@ force_persistent = False
 trace_buf = None        # tools/attn_trace.py: an int32 CUDA tensor of 16 words per logical workgroup (read by -DSAGE_ATTN_TRACE=1 builds only)
 
 
-def attn_attr(device: torch.device, is_causal, n_items: int, exact_scores: bool = False):
+def attn_attr(device: torch.device, is_causal, n_items: int, exact_scores: bool = False, packed: bool = False):
     """The ``attr`` argument of an attention entry point for a call of ``n_items`` work items: NULL, or a ``SageLaunchAttr`` with the launch
     workspace (``attn_launch_ws``) and / or the exact FP8 score form.  The returned object owns the workspace tensor: keep it until the C
     call has returned (the launch then runs in stream order behind the memset)."""
-    ws = attn_launch_ws(device, is_causal, n_items if not force_persistent else max(n_items, _PERSISTENT_MIN_ITEMS))
+    ws = attn_launch_ws(device, is_causal, n_items if not force_persistent else max(n_items, _PERSISTENT_MIN_ITEMS), packed)
     return _cabi.launch_attr(ws, exact_scores=exact_scores, force_persistent=force_persistent and ws is not None, grid_out=grid_probe,
                              trace=trace_buf, trace_wgs=0 if trace_buf is None else trace_buf.numel() // 16)
 

@@ -232,9 +232,10 @@ def test_persistent_route_200_launches_on_two_streams_equal_the_ordinary_launch(
     assert bad == 0, f"{name}: {bad} of 200 persistent launches differ from the ordinary launch"
 
 
-def test_persistent_route_varlen_200_launches_equal_the_ordinary_launch(route, forced_persistent, monkeypatch):
+@pytest.mark.parametrize("causal", [False, True])
+def test_persistent_route_varlen_200_launches_equal_the_ordinary_launch(route, forced_persistent, monkeypatch, causal):
     """The packed (varlen) launch over the device-built work list on the ticket route: the logical grid comes from the plan's header on the
-    device, items differ in length by two orders of magnitude."""
+    device, items differ in length by two orders of magnitude.  Causal too (round 5): the causal kernels of this route carry the loop."""
     ops, probe = forced_persistent
     lens = [4096, 1, 640, 129, 3000, 64, 1500, 777, 2100]
     total = sum(lens)
@@ -243,7 +244,7 @@ def test_persistent_route_varlen_200_launches_equal_the_ordinary_launch(route, f
     k = (torch.randn(total, 4, 128, generator=g) + torch.randn(1, 4, 128, generator=g)).to(BF16).to(DEV)
     v = torch.randn(total, 4, 128, generator=g).to(BF16).to(DEV)
     cu = torch.nn.functional.pad(torch.tensor(lens).cumsum(0), (1, 0)).to(torch.int32).to(DEV)
-    fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=False)
+    fn = lambda: sa.sageattn_varlen(q, k, v, cu, cu, max(lens), max(lens), is_causal=causal)
     monkeypatch.setattr(ops, "_PERSISTENT", False)
     want = fn()
     torch.cuda.synchronize()

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 CS=sageattention_amd/csrc
-SRCS="${VARIANT_SRC:-$(cd $CS && ls sage_attn_d*.hip) sage_attn.hip}"
+SRCS="${VARIANT_SRC:-$(cd $CS && ls sage_attn_d*.hip | tr '\n' ' ') sage_attn.hip}"
 mkdir -p variants
 make -C $CS -j8 -s
 OTHERS=""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch the attention kernel only (pre-quantised operands) a few times -- the target of PMC passes.
-usage: run_kernel.py [config] [reps]"""
+usage: run_kernel.py [config | c4 | c4nc | c2t] [reps]"""
 import os
 import sys
 
@@ -25,6 +25,17 @@ if name in ("c4", "c4nc"):        # BASELINE.json configs[3]: the attention laun
     torch.cuda.synchronize()
     for _ in range(reps):
         core._varlen_attend(st)
+    torch.cuda.synchronize()
+    print("done")
+    sys.exit(0)
+if name == "c2t":                  # the Triton-named API at the C2 shape: the attention launch alone (per-block Q quantised in the prologue)
+    from sageattention_amd import core, quant as sq
+    cfg = bench.CONFIGS["c2"]
+    q, k, v = bench.make_inputs(cfg, dev, 1234)
+    km_s, k8, ks, vimg, _, _ = sq.prepass_kv_fp8(k, v, "HND", smooth_k=True, qk_quant_gran="per_block_triton", v_fp16=True)
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        core._attn_fused_qblock(q, k8, vimg, ks, "HND", True, cfg["D"] ** -0.5 * sq.LOG2E, False)
     torch.cuda.synchronize()
     print("done")
     sys.exit(0)
