@@ -541,6 +541,79 @@ def run_replay(args, cfg, device, rank, world, dist_on):
             "o_shape_rank0": list(o.shape)}))
 
 
+def rank_record(rank, local_rank, have_gpu=True):
+    """What a rank reports about itself (gathered on rank 0 into `ranks_seen`, so that a scaling record proves N ranks on N GPUs)."""
+    if not have_gpu:
+        return {"rank": rank, "local_rank": local_rank, "device": None, "device_count": 0, "name": "cpu (dist check)", "pci_bus_id": None,
+                "uuid": f"cpu-{rank}", "pid": os.getpid()}
+    props = torch.cuda.get_device_properties(local_rank)
+    return {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "device_count": torch.cuda.device_count(),
+            "name": torch.cuda.get_device_name(local_rank), "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+            "pid": os.getpid()}
+
+
+def check_ranks(gathered, world, backend):
+    """`ranks_seen` of a run from the gathered rank records; over RCCL every rank must sit on a device of its own."""
+    import torch.distributed as dist
+    seen = {"world_size": dist.get_world_size() if dist.is_initialized() else world, "backend": dist.get_backend() if dist.is_initialized() else backend,
+            "ranks": gathered}
+    try:
+        seen["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        seen["rccl_version"] = None
+    assert len(gathered) == world and sorted(g["rank"] for g in gathered) == list(range(world)), "a rank is missing from the gathered records"
+    if backend == "nccl":
+        devs = [(g["uuid"] or g["device"]) for g in gathered]
+        assert len(set(devs)) == world, f"ranks share a device: {devs}"
+    return seen
+
+
+def init_ranks(rank, world, local_rank, device, backend, have_gpu=True):
+    """Process group of a --gpus N run (one rank per GPU, RCCL; `gloo` for the CPU checks) and the `ranks_seen` record."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, rank_record(rank, local_rank, have_gpu))
+    return check_ranks(gathered, world, backend)
+
+
+def reduce_times(stats, world, steps):
+    """MAX over ranks of the timed regions (the contract's clock) and every rank's own kernel-only time per step."""
+    import torch.distributed as dist
+    allw = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(allw, stats)
+    per_rank_ms = [round(t[0].item() / steps * 1e3, 4) for t in allw]
+    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    return stats, per_rank_ms
+
+
+def dist_check(args, rank, world, local_rank):
+    """--dist-check: the distributed control flow of a --gpus N run on CPU ranks over gloo -- process group, rank records, the unit split of
+    every rank (shapes only), barrier, time reduction, the JSON line -- with a fake step time instead of kernels.  It exists so that the first
+    real 8-GPU run can only fail on RCCL, not on a typo in this bookkeeping (tests/test_bench_dry_run.py runs it with 8 ranks)."""
+    import torch.distributed as dist
+    seen = init_ranks(rank, world, local_rank, None, "gloo", have_gpu=False)
+    cfg = CONFIGS[args.config]
+    from sageattention_amd import shard
+    lo, hi = shard.shard_range(cfg["B"] * cfg["Hkv"] * world, rank, world)
+    dist.barrier()
+    stats = torch.tensor([0.010 * args.steps * (1.0 + 0.01 * rank), 0.012], dtype=torch.float64)       # rank r is r % slower
+    stats, per_rank_ms = reduce_times(stats, world, args.steps)
+    wall_k = stats.tolist()[0]
+    fl = flops(cfg)
+    out = {"dist_check": True, "n_gpus": world, "steps": args.steps, "ms_per_step": round(wall_k / args.steps * 1e3, 4),
+           "value": round(fl * world / (wall_k / args.steps) / 1e12, 2), "ranks_seen": seen, "ms_per_step_per_rank": per_rank_ms,
+           "units_of_this_rank": [lo, hi]}
+    if rank == 0:
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,6 +630,7 @@ def main():
     ap.add_argument("--replay-layers", type=int, default=42)
     ap.add_argument("--replay-steps", type=int, default=50)
     ap.add_argument("--dry-run-ranks", type=int, default=0, help="walk the N-rank split of the configuration on the host (no GPU) and print it")
+    ap.add_argument("--dist-check", action="store_true", help="run the distributed bookkeeping of a --gpus N launch on CPU ranks over gloo (no GPU, no kernels)")
     args = ap.parse_args()
 
     if args.dry_run_ranks:
@@ -568,6 +642,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    if args.dist_check:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        dist_check(args, rank, world, local_rank)
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # dry-run aid for a 1-GPU box: SAGE_BENCH_BACKEND=gloo puts every rank on cuda:0 and uses gloo for the
@@ -580,27 +658,7 @@ def main():
     ranks_seen = None
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        # what this run really was: every rank reports the device it is bound to; rank 0 prints the list (and, over RCCL,
-        # insists on one distinct device per rank) so that a scaling record proves N ranks on N GPUs
-        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
-                "device_count": torch.cuda.device_count(), "name": torch.cuda.get_device_name(local_rank),
-                "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None),
-                "uuid": str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", "")), "pid": os.getpid()}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        ranks_seen = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered}
-        try:
-            ranks_seen["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
-        except Exception:
-            ranks_seen["rccl_version"] = None
-        if backend == "nccl":
-            devs = [(g["uuid"] or g["device"]) for g in gathered]
-            assert len(set(devs)) == world, f"ranks share a device: {devs}"
+        ranks_seen = init_ranks(rank, world, local_rank, device, backend)
 
     from sageattention_amd import _cabi
     _cabi.load()
@@ -630,10 +688,7 @@ def main():
     stats = torch.tensor([wall_k, wall_e], dtype=torch.float64, device=device)
     per_rank_ms = None
     if dist_on:
-        allw = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(allw, stats)
-        per_rank_ms = [round(t[0].item() / args.steps * 1e3, 4) for t in allw]
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        stats, per_rank_ms = reduce_times(stats, world, args.steps)
     wall_k, wall_e = stats.tolist()
 
     fl = flops(cfg)

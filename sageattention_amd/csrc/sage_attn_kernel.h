@@ -179,7 +179,9 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 // ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
 // SFOLD (FP8 PV only): true = the bias of the score's bit pattern is folded into the scale FMA in every tile of the launch, false = the exact
 // subtraction (see SAGE_FOLDBIAS above); FP16-PV instantiations pass true and fold in their pipelined loop only, as since round 4.
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true>
+// CPERS: the persistent ticket loop compiled into a CAUSAL instantiation (the packed route's launches over the work list; non-causal unmasked
+// instantiations always carry it).
+template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true, bool CPERS = false>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
 sage_attn_kernel(const AttnParams p_arg)
 {
@@ -211,10 +213,10 @@ sage_attn_kernel(const AttnParams p_arg)
     //      address serialise at ~200 ns each, and the 64 workgroups of an XCD finish equal items together.
     //      Causal launches keep the hardware's dispatch: their work order pairs a long and a short block on a CU through the order in which
     //      freed slots are refilled, and tickets lose that (measured: +2.6 % at C3, +7 % at C2).
-    // (round 5: the loop is also in the causal kernels of the packed / varlen route -- QF 3 / 4, per-block Q quantised in the prologue --, whose
-    //  launches over the device-built work list gain 2.9 % from it at C4; dense causal launches lose 0.1 ... 7.5 % and never take it:
-    //  profiles/r5_pers_causal_probe.txt)
-    constexpr bool PERS_OK = (!CAUSAL || (QF >= 3 && SAGE_PERS_QF != 0) || SAGE_PERS_CAUSAL != 0) && MASK == 0;
+    // (round 5: the packed / varlen route's CAUSAL launches over the device-built work list take the route too -- +2.2 ... 2.9 % at C4 -- through
+    //  instantiations of their own (CPERS); dense causal launches lose 0.1 ... 7.5 % with tickets and the loop's mere presence costs the dense
+    //  Triton-API causal kernel 1.3 %, so their instantiations stay without it: profiles/r5_pers_causal_probe.txt, r5_run_c_qf_pers_ab.txt)
+    constexpr bool PERS_OK = (!CAUSAL || CPERS || SAGE_PERS_CAUSAL != 0) && MASK == 0;
     const bool pers = PERS_OK && p.sched != nullptr;
     __shared__ int s_ticket[2];                 // (two slots, alternating: a wave may still be reading the previous ticket when wave 0 posts the next)
     int tpar = 0;
@@ -1733,8 +1735,9 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
     constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
     using C = TileCfg<D, PV_FP8, NH>;
     // causal launches take the ticket route only over a packed batch's work list (items of very different lengths, heaviest first: +2.9 % at
-    // C4); dense causal launches keep the hardware's dispatch, which their work order is built on (-0.1 ... -7.5 % with tickets)
-    const bool pers = !v.causal || SAGE_PERS_CAUSAL != 0 || (SAGE_PERS_QF != 0 && v.qf >= 3 && p.cu_q != nullptr && p.work_items != nullptr);
+    // C4), in instantiations of their own (CPERS); dense causal launches keep the hardware's dispatch, which their work order is built on
+    const bool packed_list = p.cu_q != nullptr && p.work_items != nullptr;
+    const bool pers = !v.causal || SAGE_PERS_CAUSAL != 0;
     if (v.mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, tile product folded into the FP32 output
         if constexpr (!PV_FP8) {
             using CM = TileCfg<D, false, 1>;
@@ -1753,6 +1756,10 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
     }
     if (v.qf == 3 || v.qf == 4) {      // per-block Q in the prologue: the Triton-named API's kernels (FP16 PV, per-block k scales), dense or varlen
         if constexpr (!PV_FP8) {
+            if (v.causal && packed_list && SAGE_PERS_QF != 0) {
+                if (v.qf == 3) return launch_kernel<sage_attn_kernel<D, false, true, false, true, NH, 0, 3, true, true>>(C::LDS_BYTES, p, nwork, l, true);
+                return launch_kernel<sage_attn_kernel<D, false, true, false, true, NH, 0, 4, true, true>>(C::LDS_BYTES, p, nwork, l, true);
+            }
 #define SAGE_FQB(C_, F_) if (v.causal == C_ && v.qf == F_) return launch_kernel<sage_attn_kernel<D, false, C_, false, true, NH, 0, F_>>(C::LDS_BYTES, p, nwork, l, pers);
             SAGE_FQB(false, 3) SAGE_FQB(false, 4) SAGE_FQB(true, 3) SAGE_FQB(true, 4)
 #undef SAGE_FQB

@@ -255,6 +255,7 @@ SAGE_API int sage_varlen_plan(const int32_t *cu_seqlens_q, const int32_t *cu_seq
     p.cu_qs = cu_q_scale; p.cu_ks = cu_k_scale; p.order = seq_order; p.items = work_items;
     p.slab_first = slab_first; p.slab_seq = slab_seq; p.hdr = hdr;
     p.items_cap = work_items_cap; p.slab_cap = slab_seq_cap;
+    p.forced_group = sage::work_order() > 0 ? sage::work_order() : -1;
     return check_launch(sage::launch_varlen_plan(p, static_cast<hipStream_t>(stream)), "sage_varlen_plan launch");
 }
 // host-side view of the work list (csrc/sage_work_order.h, the functions varlen_plan_kernel runs; no GPU needed): lq / lk are HOST arrays of

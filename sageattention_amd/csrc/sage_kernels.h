@@ -112,6 +112,7 @@ struct VarlenPlanParams {
                                          // (index nseq: rows cu_k[nseq] .. total_k, index nseq + 1: rows 0 .. cu_k[0]) that only the K mean reads
     int32_t *slab_seq;                   // nullable [nslab]: slab -> segment (sequence, or nseq / nseq + 1 for the gaps)
     int32_t *hdr;                        // nullable [kVarlenHdrWords]
+    int forced_group;                    // work_order() when > 0 (experiments: heads per XCD group of the attention launch's plan), else -1
     int items_cap, slab_cap;             // (sequence, query block) pairs `items` holds, entries of `slab_seq`: counts derived from cu_seqlens on the
                                          // device are clamped to them (hdr reports the clamped counts), so an inconsistent cu_seqlens cannot write past
 };

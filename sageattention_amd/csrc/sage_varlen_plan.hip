@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(1024) varlen_plan_kernel(const VarlenPlanParam
         if (p.slab_first != nullptr) { p.slab_first[0] = 0; p.slab_first[nseq + 1] = nslab_seq + nslab_tail; p.slab_first[nseq + 2] = nslab; }
         if (p.hdr != nullptr) {
             WorkOrder w;
-            plan_varlen_order(w, p.Hq, p.Hq / p.Hkv, nitems, (long)max_lk, p.head_dim, p.pv_fp8 != 0);
+            plan_varlen_order(w, p.Hq, p.Hq / p.Hkv, nitems, (long)max_lk, p.head_dim, p.pv_fp8 != 0, p.forced_group);
             p.hdr[0] = nitems; p.hdr[1] = w.group; p.hdr[2] = w.fold; p.hdr[3] = w.left;
             p.hdr[4] = nslab; p.hdr[5] = max_lk; p.hdr[6] = p.cu_k[nseq] - p.cu_k[0]; p.hdr[7] = max(nslab - nslab_seq, 0);
         }

@@ -138,10 +138,12 @@ SAGE_HD int varlen_item_rank(const int *lq, const int *lk, int nseq, int s, int 
 
 // the launch plan over that list: group / fold / left as for a dense causal launch of `nheads` = Hq heads with `nitems` blocks each,
 // the group rounded up to whole GQA groups (their query heads share one K/V stream at no L2 cost); returns the grid size
-SAGE_HD int plan_varlen_order(WorkOrder &w, int nheads, int gqa_group, int nitems, long max_kv_len, int head_dim, bool pv_fp8)
+// (`forced`: -1 automatic, n > 0 groups of n heads -- sage_set_work_order / SAGE_ORDER_GROUP, experiments)
+SAGE_HD int plan_varlen_order(WorkOrder &w, int nheads, int gqa_group, int nitems, long max_kv_len, int head_dim, bool pv_fp8, int forced = -1)
 {
     if (nitems <= 0) { w.group = 1; w.fold = 0; w.left = nheads & 7; return 0; }
-    const int grid = plan_work_order(w, nheads, nitems, max_kv_len, head_dim, pv_fp8, -1);
+    const int grid = plan_work_order(w, nheads, nitems, max_kv_len, head_dim, pv_fp8, forced > 0 ? forced : -1);
+    if (forced > 0) { w.fold = 0; return grid; }          // (a forced group is taken as it is: no rounding up to whole GQA groups)
     const int hpx = nheads >> 3;
     if (gqa_group > 1 && hpx > 0) {
         int g = ((w.group + gqa_group - 1) / gqa_group) * gqa_group;

@@ -59,3 +59,39 @@ def test_dry_run_command_line():
     assert out.returncode == 0, out.stderr[-1000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])["dry_run"]
     assert d["world"] == 8 and d["scaling"] == "strong" and [r["units"][1] - r["units"][0] for r in d["ranks"]] == [12] * 8
+
+
+def test_rank_records_are_checked():
+    """`ranks_seen` of a --gpus N run: every rank present once, and over RCCL one distinct device per rank."""
+    recs = [dict(rank=r, local_rank=r, device=r, device_count=8, name="MI355X", pci_bus_id=None, uuid=f"GPU-{r:02d}", pid=100 + r) for r in range(8)]
+    seen = bench.check_ranks(recs, 8, "nccl")
+    assert seen["world_size"] == 8 and len(seen["ranks"]) == 8 and seen["backend"] == "nccl"
+    dup = [dict(r) for r in recs]
+    dup[5]["uuid"] = dup[2]["uuid"]
+    with pytest.raises(AssertionError, match="share a device"):
+        bench.check_ranks(dup, 8, "nccl")
+    bench.check_ranks(dup, 8, "gloo")                                  # (the one-GPU gloo dry run shares cuda:0 on purpose)
+    with pytest.raises(AssertionError, match="missing"):
+        bench.check_ranks(recs[:7] + [recs[0]], 8, "nccl")
+
+
+def test_dist_check_with_eight_cpu_ranks():
+    """The driver's 8-GPU launch line on CPU ranks: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8` with
+    --dist-check runs bench.py's process-group set-up, rank records, unit split, barrier and MAX-over-ranks time reduction over gloo."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dist-check"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dist_check"] and d["n_gpus"] == 8 and d["ranks_seen"]["world_size"] == 8 and d["ranks_seen"]["backend"] == "gloo"
+    assert sorted(r["rank"] for r in d["ranks_seen"]["ranks"]) == list(range(8))
+    assert len(d["ms_per_step_per_rank"]) == 8 and d["ms_per_step"] == pytest.approx(max(d["ms_per_step_per_rank"]), rel=1e-3)
+    assert d["ms_per_step"] == pytest.approx(10.0 * 1.07, rel=1e-3)                # the slowest (fake) rank decides
+    cfg = bench.CONFIGS["c3"]
+    assert d["value"] == pytest.approx(bench.flops(cfg) * 8 / (d["ms_per_step"] * 1e-3) / 1e12, rel=1e-3)
