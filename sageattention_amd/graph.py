@@ -1,7 +1,8 @@
 """HIP-graph replay of the dense ``sageattn()`` pipeline for launch-bound shapes.
 
-One ``sageattn()`` call is seven kernel launches and eight allocations: ~70 us of host work, more than the GPU
-needs below N ~ 2k.  The dense pipeline has no host synchronisation and launches on the caller's stream, so it can
+One ``sageattn()`` call is two kernel launches (the one-launch K / V pre-pass, the attention kernel with the Q quantiser in its
+prologue; three with ``return_lse``'s correction matmul) and about eight allocations: tens of microseconds of host work, more than the
+GPU needs below N ~ 2k.  The dense pipeline has no host synchronisation and launches on the caller's stream, so it can
 be captured once per (shape, dtype, flags) and replayed with one ``hipGraphLaunch``.  The caller writes the inputs
 into the graph's static tensors (``.q .k .v``, e.g. as the output buffers of its projection GEMMs) or lets
 ``__call__`` copy them in.

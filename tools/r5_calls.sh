@@ -1,0 +1,47 @@
+#!/bin/bash
+# The gpurun calls of round 5, one function each (usage on the GPU box: bash tools/r5_calls.sh <call1|call2|call3|call4|final>).
+# Every call writes under gpurun_out/<tag>/; what was kept is under profiles/r5_*.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+suite() { timeout 1200 python -m pytest tests -m gpu -q $1 > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; grep -v "Warning\|warnings.warn\|^  " $out/pytest.log | tail -8; cp gpurun_out/parity_report.json $out/ 2>/dev/null; }
+bench_default() { timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc $?"; cut -c1-300 $out/bench_default.json; }
+
+call1() {   # the ABI-19 / folded-score build: suite, bench line, then the causal ticket-loop probe (-DSAGE_PERS_CAUSAL=1 variant), each config its own process
+  out=gpurun_out/r5a; mkdir -p $out; suite -x; bench_default
+  for c in n2k c3 c2 d64 c4; do
+    SAGE_GFX950_LIB=$PWD/variants/libsage_gfx950_perscausal.so timeout 120 python tools/pers_causal_probe.py $c 30 > $out/probe_$c.log 2>&1
+    echo "probe $c rc $?"; grep -v amdgpu.ids $out/probe_$c.log | tail -6
+  done
+}
+call2() {   # suite, pre-pass / attention overlap probe, bench line, then ROUND 4's tree (variants/r4tree = git worktree of 2844541, patched as
+            # profiles/r5_pers_causal_probe.txt says) with its ticket loop in the causal kernels
+  out=gpurun_out/r5b; mkdir -p $out; suite ""
+  for c in c2 c3; do timeout 200 python tools/overlap_probe.py $c 20 2>&1 | grep -v amdgpu.ids | tee $out/overlap_$c.txt; done
+  bench_default
+  for c in n2k c3 c2 d64; do
+    (cd variants/r4tree && timeout 120 python r4_probe.py $c 30) > $out/r4probe_$c.log 2>&1
+    echo "r4 probe $c rc $?"; grep -v amdgpu.ids $out/r4probe_$c.log | tail -7
+  done
+}
+call3() {   # suite; A/B of the ticket loop in the packed route's causal kernels (variant noqfpers = -DSAGE_PERS_QF=0); PMC passes per configuration; bench line
+  out=gpurun_out/r5c; mkdir -p $out; export SAGE_HEAD=$(cat .git_head 2>/dev/null); suite -x
+  for t in c2t c4; do timeout 200 python tools/lib_ab.py $t main noqfpers 2>&1 | grep -v amdgpu.ids | tee -a $out/qf_pers_ab.txt; done
+  timeout 900 python tools/pmc_collect.py r5c c3 c2 c2t c4 c4nc c5 pp 2>&1 | grep -v amdgpu.ids | tee $out/pmc_collect.log
+  bench_default
+}
+call4() {   # suite on the CPERS build; its A/B; C4 causal traffic vs time; the causal-ticket variant under rocprofv3 --kernel-trace
+  out=gpurun_out/r5d; mkdir -p $out; suite -x
+  for t in c2t c4; do timeout 200 python tools/lib_ab.py $t main noqfpers 2>&1 | grep -v amdgpu.ids | tee -a $out/cpers_ab.txt; done
+  TAG=r5d bash tools/c4_traffic.sh
+  s=$(date +%s)
+  SAGE_GFX950_LIB=$PWD/variants/libsage_gfx950_perscausal.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_pc -- python tools/pers_causal_probe.py c3 10 > $out/probe_c3_under_rocprofv3.log 2>&1
+  echo "rocprofv3 over the causal-ticket probe: rc $? in $(( $(date +%s) - s )) s" | tee -a $out/probe_c3_under_rocprofv3.log
+  grep -v amdgpu.ids $out/probe_c3_under_rocprofv3.log | tail -6
+  f=$(ls $out/prof_pc/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -4 "$f" | cut -c1-220 | tee $out/probe_c3_kernel_stats_head.txt; rm -rf $out/prof_pc
+}
+final() {   # the record of the round's last commit: suite, bench lines, rocprofv3 kernel-trace summaries per configuration, PMC passes
+  out=gpurun_out/r5z; mkdir -p $out; export SAGE_HEAD=$(cat .git_head 2>/dev/null); suite ""
+  TAG=r5z bash tools/final_round_runs.sh
+  timeout 900 python tools/pmc_collect.py r5z c3 c2 c2t c4 c4nc c5 pp 2>&1 | grep -v amdgpu.ids | tee $out/pmc_collect.log
+}
+"${1:-final}"
