@@ -93,9 +93,6 @@
                         // pipelined or not, so the oracle's `score_mode = folded` mirrors it rounding for rounding (oracle/sage_oracle.c) and
                         // the 2e-3 * max|o| gate is kept against that mode; SAGE_ATTR_FP8_EXACT_SCORES selects the exact form of rounds 1-4,
                         // which stays the one pinned to the reference's formula exp2(fma(s, c, -m)) (attn_utils.cuh:445-449).
-#ifndef SAGE_PKSOFT       // FP8 pipelined loops, folded score form: the scale FMA and the row-sum add of a score PAIR as one packed instruction
-#define SAGE_PKSOFT 1      // (v_pk_fma_f32 / v_pk_add_f32 on register pairs: the same IEEE operations per element, bit-identical; 4.7 against 2 x 2.9 issue cycles)
-#endif
 #ifndef SAGE_PERS_QF      // 0: A/B build without the ticket loop in the causal kernels of the packed route (QF 3 / 4)
 #define SAGE_PERS_QF 1
 #endif
@@ -1100,18 +1097,6 @@ sage_attn_kernel(const AttnParams p_arg)
                     }
                     A_FENCE();
 
-                    // Packed form (SAGE_PKSOFT, folded scores): the four exponent arguments of a group are two v_pk_fma_f32 on the score PAIRS
-                    // (consecutive accumulator registers; the scale and m + bias * c pairs are broadcast by op_sel) and the row sum two
-                    // v_pk_add_f32 -- element for element the operations of the scalar form, in its order.  v_exp_f32 / v_cvt_pk_fp8_f32 need the
-                    // halves of those pairs by name, which an asm operand cannot give: the four temporaries are PINNED to the top of the
-                    // register budget (register variables, named as pairs in the asm text).
-                    typedef float v2f_t __attribute__((ext_vector_type(2)));
-                    typedef int v2i_t __attribute__((ext_vector_type(2)));
-                    // (not in the INT8-q per-thread D = 64 instantiations that also carry the persistent loop: they sit on their 168-register budget
-                    //  and the pairs' alignment costs them five spilled registers -- they keep the scalar form, same bits)
-                    constexpr bool PKS = SFOLD && (SAGE_PKSOFT != 0) && !(D == 64 && QF == 0 && KTHREAD && PERS_OK);
-                    [[maybe_unused]] v2f_t rs2 = {0.0f, 0.0f};
-                    [[maybe_unused]] const v2f_t cs2 = {cs[0], cs[1]}, mb2 = {mb0, mb1};
                     // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
                     float rs0 = 0.0f, rs1 = 0.0f;
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
@@ -1125,25 +1110,7 @@ sage_attn_kernel(const AttnParams p_arg)
                                      "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t" PACK                                      \
                                      : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "+v"(pc[h >> 1])                               \
                                      : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"((KTHREAD && (i0 & 2)) ? mb1 : mb0))
-                        if constexpr (PKS) {
-                            // (D = 64: three waves per SIMD, 168 registers: the pair is the budget's last two; one statement, so a clobber suffices.
-                            //  Only the scale FMA is packed here: the row sum as a register PAIR cost the tightest instantiation seven spilled
-                            //  registers to alignment; the adds read the pair's halves by name, the first one a slot behind its exponential)
-                            const v2i_t s2 = {sc[sb][i0], sc[sb][i0 + 1]};
-#define SAGE_GRP_PK(SEL, PACK)                                                                                                              \
-                            asm volatile("v_pk_fma_f32 v[166:167], %3, %4, %5 " SEL " neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"                        \
-                                         "v_exp_f32 v166, v166\n\tv_exp_f32 v167, v167\n\t"                                                  \
-                                         "v_add_f32 %0, %0, v166\n\tv_add_f32 %1, %1, v167\n\t" PACK                                          \
-                                         : "+v"(rs0), "+v"(rs1), "+v"(pc[h >> 1]) : "v"(s2), "v"(cs2), "v"(mb2) : "v166", "v167")
-                            if (!(KTHREAD && (i0 & 2))) {
-                                if ((h & 1) == 0) SAGE_GRP_PK("op_sel_hi:[1,0,0]", "v_cvt_pk_fp8_f32 %2, v166, v167");
-                                else SAGE_GRP_PK("op_sel_hi:[1,0,0]", "v_cvt_pk_fp8_f32 %2, v166, v167 op_sel:[0,0,1]");
-                            } else {
-                                if ((h & 1) == 0) SAGE_GRP_PK("op_sel:[0,1,1] op_sel_hi:[1,1,1]", "v_cvt_pk_fp8_f32 %2, v166, v167");
-                                else SAGE_GRP_PK("op_sel:[0,1,1] op_sel_hi:[1,1,1]", "v_cvt_pk_fp8_f32 %2, v166, v167 op_sel:[0,0,1]");
-                            }
-#undef SAGE_GRP_PK
-                        } else if constexpr (SFOLD) {
+                        if constexpr (SFOLD) {
                             if ((h & 1) == 0) SAGE_GRP(SAGE_SCALE2_FOLD, "v_cvt_pk_fp8_f32 %4, %2, %3");
                             else SAGE_GRP(SAGE_SCALE2_FOLD, "v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
                         } else {
@@ -1166,24 +1133,8 @@ sage_attn_kernel(const AttnParams p_arg)
 #if SAGE_GRP4
                     // experiment: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
                     // can sit between the exponentials and the adds
-                    register float pu0 asm("v252"), pu1 asm("v253"), pu2 asm("v254"), pu3 asm("v255");
-                    auto g4a_pk = [&](int w) {
-                        const int sb = w >> 2, i0 = 4 * (w & 3);
-                        const v2i_t s01 = {sc[sb][i0], sc[sb][i0 + 1]}, s23 = {sc[sb][i0 + 2], sc[sb][i0 + 3]};
-                        asm volatile("v_pk_fma_f32 v[252:253], %4, %6, %7 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-                                     "v_pk_fma_f32 v[254:255], %5, %6, %7 op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
-                                     "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"
-                                     : "=v"(pu0), "=v"(pu1), "=v"(pu2), "=v"(pu3)
-                                     : "v"(s01), "v"(s23), "v"(cs2), "v"(mb2));
-                    };
-                    auto g4b_pk = [&](int w) {
-                        asm volatile("v_pk_add_f32 %0, %0, v[252:253]\n\tv_pk_add_f32 %0, %0, v[254:255]\n\t"
-                                     "v_cvt_pk_fp8_f32 %1, %2, %3\n\tv_cvt_pk_fp8_f32 %1, %4, %5 op_sel:[0,0,1]"
-                                     : "+v"(rs2), "+v"(pc[w])
-                                     : "v"(pu0), "v"(pu1), "v"(pu2), "v"(pu3));
-                    };
                     float u0, u1, u2, u3;
-                    auto g4a_sc = [&](int w) {
+                    auto g4a = [&](int w) {
                         const int sb = w >> 2, i0 = 4 * (w & 3);
 #define SAGE_G4A(SCALE4)                                                                                                                        \
                         asm volatile(SCALE4 "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"                        \
@@ -1198,14 +1149,12 @@ sage_attn_kernel(const AttnParams p_arg)
                                      "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11\n\t");
 #undef SAGE_G4A
                     };
-                    auto g4b_sc = [&](int w) {
+                    auto g4b = [&](int w) {
                         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
                                      "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
                                      : "+v"(rs0), "+v"(rs1), "+v"(pc[w])
                                      : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
                     };
-                    auto g4a = [&](int w) { if constexpr (PKS) g4a_pk(w); else g4a_sc(w); };
-                    auto g4b = [&](int w) { if constexpr (PKS) g4b_pk(w); else g4b_sc(w); };
                     if constexpr (C::DT == 4) {
                         A_PV(o[2], vf[2], pp, e8m0);
                         g4a(0); g4b(0);
@@ -1252,7 +1201,6 @@ sage_attn_kernel(const AttnParams p_arg)
                         A_FENCE(); read_v(1); A_FENCE();
                         grp(13); grp(14); grp(15);
                     }
-                    if constexpr (PKS && C::DT == 4) { rs0 = rs2[0]; rs1 = rs2[1]; }
                     l_run = l_run * alpha + (rs0 + rs1);
                     cs[0] = sm26 * (qsc * ksc_next[0][0]);
                     cs[1] = KTHREAD ? sm26 * (qsc * ksc_next[0][1]) : cs[0];
@@ -1606,7 +1554,7 @@ sage_attn_kernel(const AttnParams p_arg)
         }
     }
 #endif
-    if constexpr (PERS_OK || (D == 64 && PV_FP8)) {
+    if constexpr (PERS_OK) {
         // the general iterations' per-lane LDS offsets are re-derived here: formed before the pipelined loop they stay live across it, and the
         // D = 64 per-thread instantiation with the folded score form then spills one of them (8 bytes of scratch for one store per item)
         int lane_t = lane;
