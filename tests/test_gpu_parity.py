@@ -1381,6 +1381,38 @@ def test_persistent_launches_are_bit_identical_and_really_taken(monkeypatch):
     assert 0 < g1 < g0 and torch.equal(o1, o0)
 
 
+def test_varlen_plan_clamps_counts_to_its_outputs_capacities():
+    """sage_varlen_plan derives the item and slab counts from cu_seqlens ON THE DEVICE, while its output buffers are sized on the host from
+    the packed row counts.  A cu_seqlens that is inconsistent with those rows (last prefix far beyond them) must not write past the buffers:
+    the counts are clamped to the capacities handed over (hdr reports the clamped counts), guard words behind the buffers stay intact."""
+    lib = _cabi.load()
+    nseq, total = 3, 1000
+    cu = torch.tensor([0, 300, 700, 200000], dtype=torch.int32, device=DEV)          # claims 200000 rows; the tensors have 1000
+    items_cap = (total + 127) // 128 + nseq
+    slab_cap = (total + 511) // 512 + nseq + 2
+    GUARD = 0x5A5A5A5A
+    items = torch.full((2 * items_cap + 64,), GUARD, dtype=torch.int32, device=DEV)
+    slab_seq = torch.full((slab_cap + 64,), GUARD, dtype=torch.int32, device=DEV)
+    cu_ks = torch.empty(nseq + 1, dtype=torch.int32, device=DEV)
+    slab_first = torch.empty(nseq + 3, dtype=torch.int32, device=DEV)
+    hdr = torch.empty(8, dtype=torch.int32, device=DEV)
+    rc = lib.sage_varlen_plan(cu.data_ptr(), cu.data_ptr(), nseq, total, 128, 64, 1, 8, 4, 128, 0, None, cu_ks.data_ptr(), None,
+                              items.data_ptr(), items_cap, slab_first.data_ptr(), slab_seq.data_ptr(), slab_cap, hdr.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "sage_varlen_plan")
+    torch.cuda.synchronize()
+    h = hdr.cpu().numpy()
+    assert 0 < h[0] <= items_cap and 0 < h[4] <= slab_cap, h
+    assert (items[2 * items_cap:] == GUARD).all() and (slab_seq[slab_cap:] == GUARD).all()
+    it = items[:2 * int(h[0])].view(-1, 2).cpu().numpy()
+    assert ((it[:, 0] >= 0) & (it[:, 0] < nseq)).all() and (slab_seq[:int(h[4])].cpu().numpy() < nseq + 2).all()
+    # a consistent batch is untouched by the clamp: the plan of the same lengths with true row counts
+    ok = sq.varlen_plan(torch.tensor([0, 300, 700, 1000], dtype=torch.int32, device=DEV), torch.tensor([0, 300, 700, 1000], dtype=torch.int32, device=DEV),
+                        total_q=total, total_k=total, is_causal=True, Hq=8, Hkv=4)
+    torch.cuda.synchronize()
+    assert int(ok.hdr[0].item()) == 3 + 4 + 3 and int(ok.hdr[4].item()) == 1 + 1 + 1
+
+
 def test_varlen_with_more_sequences_than_the_plan_takes(oracle_mod):
     """More than sage_varlen_plan_max_seqs() sequences: no plan, so torch prefix sums, an on-device argsort for the unit order, the kernel
     sequence, the Q quantiser fused in the attention prologue -- exercised end to end (round 3 only checked that the planner returns None).

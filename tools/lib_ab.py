@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of library builds on ONE kernel target of tools/run_kernel.py's kind, interleaved in one process (HIP events, medians).
-usage: lib_ab.py <c2t|c4|c4nc|c3|c2|...> tagA tagB ...      ('main' = the in-tree library, other tags = variants/libsage_gfx950_<tag>.so)"""
+usage: lib_ab.py <c2t|c4|c4nc|c3|c2|e2e:c5|...> tagA tagB ...      ('main' = the in-tree library, other tags = variants/libsage_gfx950_<tag>.so)"""
 import os
 import sys
 
@@ -34,6 +34,11 @@ elif name == "c2t":
     q, k, v = bench.make_inputs(cfg, dev, 1234)
     km_s, k8, ks, vimg, _, _ = sq.prepass_kv_fp8(k, v, "HND", smooth_k=True, qk_quant_gran="per_block_triton", v_fp16=True)
     step = lambda: core._attn_fused_qblock(q, k8, vimg, ks, "HND", True, cfg["D"] ** -0.5 * sq.LOG2E, False)[0]
+    fl = bench.flops(cfg)
+elif name.startswith("e2e:"):             # the whole call (default route: fused pre-pass + fused-Q attention)
+    cfg = bench.CONFIGS[name[4:]]
+    q, k, v = bench.make_inputs(cfg, dev, 1234)
+    step = lambda: bench.e2e_step(cfg, q, k, v)
     fl = bench.flops(cfg)
 else:
     cfg = bench.CONFIGS[name]

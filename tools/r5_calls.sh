@@ -1,5 +1,5 @@
 #!/bin/bash
-# The gpurun calls of round 5, one function each (usage on the GPU box: bash tools/r5_calls.sh <call1|call2|call3|call4|final>).
+# The gpurun calls of round 5, one function each (usage on the GPU box: bash tools/r5_calls.sh <call1|call2|call3|call4|call5|final>).
 # Every call writes under gpurun_out/<tag>/; what was kept is under profiles/r5_*.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -38,6 +38,15 @@ call4() {   # suite on the CPERS build; its A/B; C4 causal traffic vs time; the 
   echo "rocprofv3 over the causal-ticket probe: rc $? in $(( $(date +%s) - s )) s" | tee -a $out/probe_c3_under_rocprofv3.log
   grep -v amdgpu.ids $out/probe_c3_under_rocprofv3.log | tail -6
   f=$(ls $out/prof_pc/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -4 "$f" | cut -c1-220 | tee $out/probe_c3_kernel_stats_head.txt; rm -rf $out/prof_pc
+}
+call5() {   # packed softmax instructions (SAGE_PKSOFT): bit-identity and timing against the build without (variant nopk), both orders of measurement
+  out=gpurun_out/r5e; mkdir -p $out
+  for t in c3 d64f8 n2k e2e:c5 e2e:c3; do
+    timeout 300 python tools/lib_ab.py $t main nopk 2>&1 | grep -v amdgpu.ids | tee -a $out/pksoft_ab.txt
+    timeout 300 python tools/lib_ab.py $t nopk main 2>&1 | grep -v amdgpu.ids | tee -a $out/pksoft_ab.txt
+  done
+  for t in c2t; do timeout 200 python tools/lib_ab.py $t noqfpers main 2>&1 | grep -v amdgpu.ids | tee -a $out/cpers_ab_reversed.txt; done
+  suite -x
 }
 final() {   # the record of the round's last commit: suite, bench lines, rocprofv3 kernel-trace summaries per configuration, PMC passes
   out=gpurun_out/r5z; mkdir -p $out; export SAGE_HEAD=$(cat .git_head 2>/dev/null); suite ""
