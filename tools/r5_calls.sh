@@ -48,6 +48,13 @@ call5() {   # packed softmax instructions (SAGE_PKSOFT): bit-identity and timing
   for t in c2t; do timeout 200 python tools/lib_ab.py $t noqfpers main 2>&1 | grep -v amdgpu.ids | tee -a $out/cpers_ab_reversed.txt; done
   suite -x
 }
+call6() {   # what lies between the kernels of a call: rocprofv3 kernel-trace timestamps of 30 back-to-back sageattn() calls (C3, C2)
+  out=gpurun_out/r5f; mkdir -p $out
+  for c in c3 c2; do
+    rm -rf $out/tr; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/tr -- python tools/call_gaps.py run $c > $out/tr.log 2>&1
+    echo "== $c" | tee -a $out/call_gaps.txt; python tools/call_gaps.py parse $out/tr | tee -a $out/call_gaps.txt; rm -rf $out/tr
+  done
+}
 final() {   # the record of the round's last commit: suite, bench lines, rocprofv3 kernel-trace summaries per configuration, PMC passes
   out=gpurun_out/r5z; mkdir -p $out; export SAGE_HEAD=$(cat .git_head 2>/dev/null); suite ""
   TAG=r5z bash tools/final_round_runs.sh
