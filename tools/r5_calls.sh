@@ -55,9 +55,13 @@ call6() {   # what lies between the kernels of a call: rocprofv3 kernel-trace ti
     echo "== $c" | tee -a $out/call_gaps.txt; python tools/call_gaps.py parse $out/tr | tee -a $out/call_gaps.txt; rm -rf $out/tr
   done
 }
-final() {   # the record of the round's last commit: suite, bench lines, rocprofv3 kernel-trace summaries per configuration, PMC passes
+final() {   # the record of the round's last commit: suite (+ the FP8 tests once more with the EXACT score form as the process default), bench lines,
+            # rocprofv3 kernel-trace summaries per configuration, PMC passes (+ the exact form's C3 / C5 for the instruction-count difference)
   out=gpurun_out/r5z; mkdir -p $out; export SAGE_HEAD=$(cat .git_head 2>/dev/null); suite ""
-  TAG=r5z bash tools/final_round_runs.sh
+  SAGE_FP8_SCORES=exact timeout 900 python -m pytest tests -m gpu -q -k "f8 or fp8 or config3 or config5 or score or 32k or split or sm90 or edge or random or smooth_v or soak or persistent" > $out/pytest_exact.log 2>&1
+  echo "pytest (SAGE_FP8_SCORES=exact) rc $?" | tee -a $out/pytest_exact.log; tail -3 $out/pytest_exact.log
+  s0=$(date +%s); TAG=r5z bash tools/final_round_runs.sh; echo "final_round_runs: $(( $(date +%s) - s0 )) s"
   timeout 900 python tools/pmc_collect.py r5z c3 c2 c2t c4 c4nc c5 pp 2>&1 | grep -v amdgpu.ids | tee $out/pmc_collect.log
+  SAGE_FP8_SCORES=exact timeout 400 python tools/pmc_collect.py r5z_exact c3 c5 2>&1 | grep -v amdgpu.ids | tee $out/pmc_collect_exact.log
 }
 "${1:-final}"
