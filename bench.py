@@ -206,10 +206,10 @@ def prequantize(cfg, q, k, v):
 
 
 def kernel_only_step(cfg, ops, sm_scale=None):
-    from sageattention_amd import core
+    from sageattention_amd import core, ops as sa_ops
     q8, qs, k8, ks, vimg, vscale, gran, q_warp, sm_log2 = ops
     return core._attn_dense(cfg["pv"] == "fp8", q8, k8, vimg, vscale, qs, ks, _dtype(cfg), "HND", cfg["causal"],
-                            gran, q_warp, sm_log2, cfg["pv"] == "fp8", False)[0]
+                            gran, q_warp, sm_log2, cfg["pv"] == "fp8", False, exact_scores=sa_ops.fp8_exact(None))[0]      # (the process default: SAGE_FP8_SCORES)
 
 
 def e2e_step(cfg, q, k, v):

@@ -90,7 +90,7 @@ def qk_int8_sv_f8_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: tor
     _, _, _, _, o_sb, o_sh, o_sl = _dims(output, tensor_layout)
     lse = _lse_alloc(query, tensor_layout, return_lse)
     code = _cabi.DTYPE_F16 if output.dtype == torch.float16 else _cabi.DTYPE_BF16
-    attr = attn_attr(query.device, is_causal, B * Hq * ((Lq + 127) // 128), exact_scores or _FP8_EXACT)
+    attr = attn_attr(query.device, is_causal, B * Hq * ((Lq + 127) // 128), exact_scores)      # (core resolves SAGE_FP8_SCORES; an explicit form wins)
     rc = _cabi.load().sage_attn_qk_int8_pv_f8(
         _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
         _p(value_scale), _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
