@@ -199,7 +199,7 @@ SAGE_API int sage_prep_v_fp8(const void *v, void *v_image, float *v_scale, float
  *         issued in stream order -- ABI 18 zeroed it with a launch of its own in front of every call (4.8 us and a kernel boundary);
  *         two launches that may run concurrently need two buffers.  Layout: 32 words per (K|V, b, h):
  *         [0] arrivals, [1] departures, [2] give-up flag (sticky: the one word the kernel never clears): set if a workgroup waited
- *         30 ms of wall-clock time for the other slabs of its
+ *         30 ms of wall-clock time (and at least 2^14 polls: time spent context-switched out does not count) for the other slabs of its
  *         head in vain (the co-residency assumption below was violated).  Such a workgroup computes the head's statistics itself --
  *         it re-reads the whole head, slab by slab, through the same summation order -- so the outputs are the same bits as ever; the
  *         launch is slow, not wrong (rounds 2-3 wrote NaN instead).  sage_prepass_failed_heads(sync, B, H, stream) synchronises the

@@ -277,14 +277,18 @@ __device__ __forceinline__ void prepass_body(const PrepassParams &p, PrepassLds<
                 // stream's kernels -- this workgroup stops waiting, records it (word 2 of the head's sync line, the caller's host word) and
                 // computes the head's statistics ITSELF below; nothing it writes depends on another workgroup then
                 const unsigned want = (unsigned)nslab + (p.debug_fail ? 1u : 0u);
-                // a TIME bound (the 100 MHz wall clock: 30 ms; the test hook 0.2 ms), not a poll count: how long a poll takes depends on how
-                // contended the coherence point is, and the bound is what separates "a slow head-mate" from "a head-mate that is not running"
+                // a TIME bound (the 100 MHz wall clock: 30 ms; the test hook 0.2 ms) AND a minimum of polls.  Time, because how long a poll takes
+                // depends on how contended the coherence point is and the bound is what separates "a slow head-mate" from "a head-mate that is
+                // not running"; polls as well, because the wall clock keeps running while this wave is context-switched out (another process's
+                // time slice on a shared device): a wave that comes back after 30 ms has not WAITED 30 ms, and its head-mates come back with it
+                // (seen once: a give-up in the two-stream soak on a box that ran the suite 60 % slower than its neighbours)
                 const long long bound = p.debug_fail ? 20000LL : 3000000LL;
+                const unsigned min_polls = p.debug_fail ? (1u << 8) : (1u << 14);
                 const long long t0 = wall_clock64();
-                unsigned gave_up = 0;
+                unsigned gave_up = 0, polls = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (wall_clock64() - t0 > bound) {
+                    if (++polls > min_polls && wall_clock64() - t0 > bound) {
                         __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (p.host_flag != nullptr) __hip_atomic_store(p.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         gave_up = 1;
