@@ -1005,7 +1005,7 @@ def test_ring_steps_on_one_gpu_match_full_attention(causal):
 
 
 # ------------------------------------------------------------------------------------------------ randomized sweep + graphs
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))      # (SAGE_RANDOM_SEEDS=400: a one-off stress run)
 def test_random_shapes_vs_oracle(oracle_mod, seed):
     """Seeded random problems (shapes around the 64/128 tile edges and the steady/general loop boundary, GQA, both head
     dims, every granularity and accumulation mode, both layouts) against the oracle on identical operands."""
