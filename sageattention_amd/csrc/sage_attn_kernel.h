@@ -1210,7 +1210,9 @@ sage_attn_kernel(const AttnParams p_arg)
                 };
                 if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
                     body(sA, sB, pA, pB);
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                    // the nops carry the renamed registers as operands: the copies below are plain moves, which the compiler
+                    // otherwise schedules above the nops, i.e. into the latency of the MFMAs (inside the asm of body) that write sB
+                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sB[0]), "+v"(sB[1])::"memory");
                     sA[0] = sB[0]; sA[1] = sB[1]; pA = pB;
                 }
 #pragma nounroll
@@ -1224,7 +1226,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA, e8m0);
                 load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
-                asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                 __builtin_amdgcn_s_barrier();
             }
 #undef A_FMAN
@@ -1487,7 +1489,9 @@ sage_attn_kernel(const AttnParams p_arg)
                 };
                 if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
                     body(sA, sB, pA, pB);
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                    // the nops carry the renamed registers as operands: the copies below are plain moves, which the compiler
+                    // otherwise schedules above the nops, i.e. into the latency of the MFMAs (inside the asm of body) that write sB
+                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sB[0]), "+v"(sB[1])::"memory");
                     sA[0] = sB[0]; sA[1] = sB[1];
 #pragma unroll
                     for (int c = 0; c < 4; c++) pA[c] = pB[c];
@@ -1534,9 +1538,12 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                         for (int c = 1; c < 4; c++) A_PV16(rsacc, ones16, pA[c]);
                     }
-                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VP / 4) : "memory");
-                    if constexpr (RSMFMA) l_run += (g == 0 ? rsacc[0] : 0.0f);
+                    if constexpr (RSMFMA) {
+                        asm volatile("" : "+v"(rsacc));          // (ordered behind the nops, like sA: the sum below reads an MFMA result)
+                        l_run += (g == 0 ? rsacc[0] : 0.0f);
+                    }
                     __builtin_amdgcn_s_barrier();
                 }
             }

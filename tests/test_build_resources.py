@@ -88,3 +88,23 @@ def test_no_kernel_of_the_library_uses_scratch():
             if res.get("ScratchSize", 0) != 0 or res.get("VGPRs Spill", 0) != 0:
                 bad[f"{src}:{name}"] = res
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_no_read_of_an_asm_issued_mfma_result_inside_its_latency():
+    """The compiler's hazard recogniser does not see the MFMAs issued from inline asm, and it may move plain copies of their results up to
+    just behind the asm statement (round 5: the odd-count rename of the FP16-PV loop, above its nops).  tools/mfma_hazard_lint.py walks the
+    listing of every attention unit for such reads."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_hazard_lint as lint
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(lint.UNITS)) as ex:
+        results = dict(zip(lint.UNITS, ex.map(lambda u: lint.lint(lint.listing(u)), lint.UNITS)))
+    for unit, (findings, n_mfma) in results.items():
+        assert n_mfma >= 200, (unit, n_mfma)                   # (the walk did see the pipelined loops)
+        assert not findings, (unit, findings[:5])
+    # the lint itself: a copy two instructions behind an asm MFMA is reported, one behind enough nops is not
+    bad = "_Zk:\n\t;;#ASMSTART\n\tv_mfma_i32_32x32x32_i8 v[96:111], v[0:3], v[4:7], v[96:111]\n\t;;#ASMEND\n\tv_add_f32_e32 v1, v2, v3\n\tv_mov_b32_e32 v64, v97\n"
+    ok = bad.replace("v_add_f32_e32 v1, v2, v3", "s_nop 15")
+    assert len(lint.lint(bad)[0]) == 1 and len(lint.lint(ok)[0]) == 0

@@ -1041,7 +1041,35 @@ def test_random_shapes_vs_oracle(oracle_mod, seed):
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
     assert err <= 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale, f"{desc}: {err:.3e} vs {scale:.3e}"
-    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3, desc
+    # (the q.km^T correction of the LSE is rounded to the input dtype: bf16 keeps 8 bits of a term of a few units -- seed 96 of a 400-seed run: 5.5e-3)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2), desc
+
+
+@pytest.mark.parametrize("L", [576, 622, 739, 1100])
+@pytest.mark.parametrize("pv,D", [("f16_two", 128), ("f16_single", 128), ("f16_single", 64), ("f8_two", 128), ("f8_two", 64)])
+def test_causal_ragged_last_block_with_an_odd_count_of_pipelined_tiles(oracle_mod, pv, D, L):
+    """Causal, Lq = Lk not a multiple of 128: only the last query block runs an ODD number of tiles through the software-pipelined loop (7, 7, 9
+    and 15 here; whole blocks always run an even number), which takes the loop's one-tile prologue and its register rename.  The rename's
+    copies of MFMA results were once scheduled by the compiler above the wait states in front of them (FP16 PV, D = 128, causal: errors of
+    1.4 % of max|o| in the last block's rows, found by seeds 94 and 174 of a 400-seed run of the test above; tools/mfma_hazard_lint.py)."""
+    dt = L & 1
+    q, k, v = rand_qkv(1, 2, 1, L, L, D, dt, seed=L, kbias=1.0)
+    fp8 = pv.startswith("f8")
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    for gran in ("per_thread", "per_warp"):
+        o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=True, pv="f8" if fp8 else "f16",
+                                                       qk_quant_gran=gran, return_lse=True, km=km,
+                                                       warpq=16 if (pv == "f16_two" and D == 128) else 32, fp8_scores=SCORES)
+        fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
+        o, lse = fn(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=True, qk_quant_gran=gran, pv_accum_dtype=PV_ACCUM[pv], return_lse=True)
+        torch.cuda.synchronize()
+        got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
+        scale = float(np.abs(ref).max())
+        bar = 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale
+        last = (L - 1) // 128 * 128
+        over = np.abs(got - ref) > bar
+        assert not over.any(), f"{pv} D{D} L{L} {gran}: {int(over.sum())} elements over the bar, {int(over[:, :, last:].sum())} of them in the last block"
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
 
 
 def test_sageattn_is_hip_graph_capturable():
