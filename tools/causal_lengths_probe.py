@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FP16-PV causal kernel on bit-exact operands vs the oracle over a list of lengths, 12 launches each: where (which rows) and how reproducibly it differs.
-Written for the stress finding of round 5 (seeds 94 / 174 of a 400-seed run; profiles/r5_run_g_stress400_odd_tiles.txt).  SAGE_LIB selects a variant library.
+Written for the stress finding of round 5 (seeds 94 / 174 of a 400-seed run; profiles/r5_run_g_stress400_odd_tiles.txt).  SAGE_GFX950_LIB selects a variant library.
 
     python tools/causal_lengths_probe.py 576 622 739 1100        (DIAG_D=64 for the other head size)"""
 import os, sys
