@@ -7,7 +7,8 @@ copies of those results up to just behind the asm statement.  Round 5 found such
 hoisted above its nops in the causal D = 128 instantiations only; wrong rows in the last query block of lengths with an odd number of
 pipelined tiles).  This script walks the compiler's listing of a unit and reports every instruction that touches the destination of an
 asm-issued MFMA fewer wait states behind it than the ISA's XDL -> VALU rule asks (8-pass MFMA: 11, 16-pass: 19), except another MFMA
-accumulating into the very same registers.  Straight-line approximation: it follows the listing, not the branches.
+accumulating into the very same registers.  Back-to-back MFMAs are modelled as the matrix pipe issues them (one per `passes` issue
+slots: the wait in front of the second one counts for the first).  It follows the listing and, where MFMAs are still pending at a branch, the branch target too.
 
     python tools/mfma_hazard_lint.py [unit.hip ...]        (default: the six attention units)"""
 import os
@@ -24,6 +25,9 @@ UNITS = ("sage_attn_d128_f8.hip", "sage_attn_d128_f8x.hip", "sage_attn_d128_f16.
          "sage_attn_d64_f16.hip")
 NEED = {"v_mfma_f32_32x32x64_f8f6f4": 19, "v_mfma_scale_f32_32x32x64_f8f6f4": 19}        # 16 passes; everything else used here: 8 passes
 NEED_DEFAULT = 11
+PASSES = {k: 16 for k in NEED}
+PASSES_DEFAULT = 8
+TAKEN_BRANCH = 2           # issue slots a taken branch costs on top of its own (assumed: the instruction buffer refills; >= 8 clocks)
 _REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
 
@@ -41,15 +45,19 @@ def _regs(text):
     return [(int(a), int(b)) if a else (int(c), int(c)) for a, b, c in _REG.findall(text)]
 
 
-def lint(asm_text):
-    """-> (list of findings, number of asm-issued MFMAs seen).  A finding: (kernel, line number, instruction, the MFMA, wait states short)."""
-    findings, n_mfma = [], 0
-    kernel, in_asm, pending = "?", False, []           # pending: [lo, hi, wait states still needed, text]
+def _parse(asm_text):
+    """-> list of (kernel, line number, text, op, operands, issued from inline asm), {label: index of the instruction behind it}"""
+    ins, labels = [], {}
+    kernel, in_asm = "?", False
     for ln, raw in enumerate(asm_text.split("\n"), 1):
         line = raw.strip()
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            kernel, pending = m.group(1), []
+            kernel = m.group(1)
+            continue
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            labels[m.group(1)] = len(ins)
             continue
         if line.startswith(";;#ASMSTART"):
             in_asm = True
@@ -63,12 +71,30 @@ def lint(asm_text):
         if not line:
             continue
         op, _, rest = line.partition(" ")
-        if op.startswith("s_") and not _REG.search(rest):
-            states = int(rest.strip() or 0) + 1 if op == "s_nop" else 1
+        ins.append((kernel, ln, line, op, [o.strip() for o in rest.split(",")] if rest.strip() else [], in_asm))
+    return ins, labels
+
+
+def _walk(ins, labels, start, pending, findings, top):
+    """Follows the listing from instruction `start`.  top: the main pass (records new asm MFMAs, forks at branches into their targets);
+    a fork only carries the MFMAs pending at its branch and ends when their windows have passed.  -> number of asm MFMAs seen"""
+    n_mfma, kernel = 0, ins[start][0] if start < len(ins) else "?"
+    busy = 0                   # passes the matrix pipe is still occupied for: an MFMA issued inside them waits for the remainder
+    for idx in range(start, len(ins)):
+        k, ln, line, op, ops, in_asm = ins[idx]
+        if k != kernel:
+            if not top:
+                return n_mfma
+            kernel, pending = k, []
+        if op.startswith("s_") and not any(_REG.search(o) for o in ops):
+            states = int(ops[0] or 0) + 1 if op == "s_nop" and ops else 1
             if op in ("s_endpgm", "s_setpc_b64"):
                 pending = []
+            if top and pending and (op.startswith("s_cbranch") or op == "s_branch") and ops and ops[0] in labels:
+                _walk(ins, labels, labels[ops[0]], [[p[0], p[1], p[2] - states - TAKEN_BRANCH, p[3]] for p in pending], findings, False)
+                if op == "s_branch":
+                    pending = []
         else:
-            ops = [o.strip() for o in rest.split(",")]
             is_mfma = op.startswith("v_mfma")
             for lo, hi, need, what in pending:
                 if need <= 0:
@@ -78,17 +104,33 @@ def lint(asm_text):
                         if a <= hi and b >= lo:
                             if is_mfma and i in (0, 3) and (a, b) == (lo, hi):      # accumulates into the same registers: hardware interlock
                                 continue
-                            findings.append((kernel, ln, line, what, need))
+                            findings.add((kernel, ln, line, what, need))
             states = 1
-            if is_mfma and in_asm:
-                n_mfma += 1
-                d = _regs(ops[0])
-                if d:
-                    pending.append([d[0][0], d[0][1], NEED.get(op, NEED_DEFAULT) + states, line])
+            if is_mfma:
+                for p in pending:               # (the stall in front of this MFMA counts for the MFMAs already issued, not for this one)
+                    p[2] -= busy
+                busy = PASSES.get(op, PASSES_DEFAULT) + 1
+                if in_asm and top:
+                    n_mfma += 1
+                    d = _regs(ops[0])
+                    if d:
+                        pending.append([d[0][0], d[0][1], NEED.get(op, NEED_DEFAULT) + states, line])
+        busy = max(0, busy - states)
         for p in pending:
             p[2] -= states
         pending = [p for p in pending if p[2] > 0]
-    return findings, n_mfma
+        if not top and not pending:
+            return n_mfma
+    return n_mfma
+
+
+def lint(asm_text):
+    """-> (list of findings, number of asm-issued MFMAs seen).  A finding: (kernel, line number, instruction, the MFMA, wait states short).
+    The walk follows the listing and, with MFMAs pending at a branch, also the branch's target (loop back-edges, skipped blocks)."""
+    ins, labels = _parse(asm_text)
+    findings = set()
+    n = _walk(ins, labels, 0, [], findings, True) if ins else 0
+    return sorted(findings, key=lambda f: f[1]), n
 
 
 def main(argv):
