@@ -231,7 +231,7 @@ def test_smooth_v_paths_vs_oracle_and_sdpa(oracle_mod, pv, causal):
                                           qk_quant_gran="per_warp", km=km, smooth_v=True, vm=vm, fp8_scores=SCORES)
     got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
     scale = float(np.abs(ref).max())
-    assert np.abs(got - ref).max() <= 2e-3 * scale + 2 ** -11 * scale
+    assert np.abs(got - ref).max() <= 2e-3 * scale + util.out_ulp(scale, dt)
     truth = util.sdpa_f32(q, k, v, causal).numpy()
     rel = util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
     REPORT[f"sdpa/smooth_v/{pv}/{'c' if causal else 'nc'}"] = dict(rel_rmse=rel, cos=util.cos_sim(got, truth))
@@ -286,7 +286,7 @@ def test_attention_kernel_vs_oracle(oracle_mod, case, causal, gran, pv):
     err = float(np.abs(got - ref).max())
     REPORT[f"kernel_vs_oracle/{name}/{'c' if causal else 'nc'}/{gran}/{pv}"] = dict(max_abs=err, max_o=scale,
                                                                                     lse=float(np.abs(lse.cpu().numpy() - lse_ref).max()))
-    out_ulp = (2 ** -8 if dt == 1 else 2 ** -11) * scale            # one output-dtype ulp at max|o|
+    out_ulp = util.out_ulp(scale, dt)            # one output-dtype ulp at max|o|
     assert err <= 2e-3 * scale + out_ulp, f"max|diff| {err:.3e} vs max|o| {scale:.3e}"
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3     # q.km^T correction is rounded to fp16/bf16
 
@@ -345,7 +345,7 @@ def test_edge_shapes_vs_oracle(oracle_mod, shape, pv, causal):
     got, ref = o.float().cpu().numpy(), util.f32(ref, dt)
     assert np.isfinite(got).all()
     scale = float(np.abs(ref).max())
-    assert np.abs(got - ref).max() <= 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale
+    assert np.abs(got - ref).max() <= 2e-3 * scale + util.out_ulp(scale, dt)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
 
 
@@ -1040,7 +1040,7 @@ def test_random_shapes_vs_oracle(oracle_mod, seed):
     assert np.isfinite(got).all(), desc
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
-    assert err <= 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale, f"{desc}: {err:.3e} vs {scale:.3e}"
+    assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{desc}: {err:.3e} vs {scale:.3e}"
     # (the q.km^T correction of the LSE is rounded to the input dtype: bf16 keeps 8 bits of a term of a few units -- seed 96 of a 400-seed run: 5.5e-3)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2), desc
 
@@ -1065,11 +1065,68 @@ def test_causal_ragged_last_block_with_an_odd_count_of_pipelined_tiles(oracle_mo
         torch.cuda.synchronize()
         got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
         scale = float(np.abs(ref).max())
-        bar = 2e-3 * scale + (2 ** -8 if dt == 1 else 2 ** -11) * scale
+        bar = 2e-3 * scale + util.out_ulp(scale, dt)
         last = (L - 1) // 128 * 128
         over = np.abs(got - ref) > bar
         assert not over.any(), f"{pv} D{D} L{L} {gran}: {int(over.sum())} elements over the bar, {int(over[:, :, last:].sum())} of them in the last block"
         assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))
+def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
+    """The seeded sweep above for the entry points it does not reach: the Triton-named API (per-block scales, Q quantised in the kernel),
+    sageattn_varlen (packed sequences of random lengths incl. 1-token and empty-query ones, cu_q != cu_k when not causal), and the sm90 entry
+    point (its own scale groups) -- each against the oracle on identical operands with the same K mean."""
+    rng = np.random.default_rng(5000 + seed)
+    kind = ("triton", "varlen", "sm90")[seed % 3]
+    D = int(rng.choice([64, 128]))
+    Hkv = int(rng.integers(1, 4))
+    Hq = Hkv * int(rng.choice([1, 2, 4]))
+    dt = int(rng.integers(0, 2))
+    causal = bool(rng.integers(0, 2))
+    pick_len = lambda: int(rng.choice([int(rng.integers(1, 200)), int(rng.integers(190, 330)), int(rng.integers(500, 1200))]))
+    if kind == "varlen":
+        nseq = int(rng.integers(1, 6))
+        lk = [pick_len() for _ in range(nseq)]
+        lq = list(lk) if causal else [int(rng.choice([0, 1, pick_len()], p=[0.1, 0.1, 0.8])) for _ in range(nseq)]
+        if sum(lq) == 0:
+            lq[0] = 3
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(sum(lq), Hq, D, generator=g).to(T(dt))
+        k = (torch.randn(sum(lk), Hkv, D, generator=g) + float(rng.random() * 2) * torch.randn(1, Hkv, D, generator=g)).to(T(dt))
+        v = torch.randn(sum(lk), Hkv, D, generator=g).to(T(dt))
+        cu_q = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32)
+        cu_k = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32)
+        desc = f"varlen lq{lq} lk{lk} Hq{Hq} Hkv{Hkv} D{D} dt{dt} causal{causal}"
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        o = sa.sageattn_varlen(qd, kd, vd, cu_q.to(DEV), cu_k.to(DEV), max(lq), max(lk), is_causal=causal)
+        torch.cuda.synchronize()
+        km = util.bits(_varlen_km(kd, cu_q.to(DEV), cu_k.to(DEV)))
+        ref = oracle_mod.sageattn_varlen(util.bits(q), util.bits(k), util.bits(v), dt, cu_q.numpy(), cu_k.numpy(), is_causal=causal, km=km)
+        _assert_vs_oracle(f"random/{seed}/{desc}", o.float().cpu().numpy(), ref, dt)
+        return
+    B = int(rng.integers(1, 3))
+    Lk = pick_len()
+    Lq = Lk if (causal and (kind == "triton" or rng.random() < 0.7)) else int(rng.integers(1, 420))
+    layout = str(rng.choice(["HND", "NHD"]))
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    desc = f"{kind} B{B} Hq{Hq} Hkv{Hkv} Lq{Lq} Lk{Lk} D{D} dt{dt} causal{causal} {layout}"
+    if kind == "triton":
+        ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
+                                                    qk_quant_gran="per_block", return_lse=True, km=km)
+        o, lse = sa.sageattn_qk_int8_pv_fp16_triton(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout,
+                                                    is_causal=causal, return_lse=True)
+    else:
+        gran = str(rng.choice(["per_warp", "per_thread"]))
+        desc += " " + gran
+        ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8", qk_quant_gran=gran,
+                                                    return_lse=True, km=km, warpq=16, blkk=128, fp8_scores=SCORES)
+        o, lse = sa.sageattn_qk_int8_pv_fp8_cuda_sm90(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout,
+                                                      is_causal=causal, qk_quant_gran=gran, pv_accum_dtype="fp32+fp32", return_lse=True)
+    torch.cuda.synchronize()
+    _assert_vs_oracle(f"random/{seed}/{desc}", to_hnd(o, layout).float().cpu().numpy(), ref, dt)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2), desc
 
 
 def test_sageattn_is_hip_graph_capturable():

@@ -78,6 +78,16 @@ def decode_v_image(img: np.ndarray, L: int, fp8: bool) -> np.ndarray:
     return out.reshape(*lead, T * 64, D)[..., :L, :]
 
 
+def out_ulp(scale: float, dtype_code: int) -> float:
+    """One ulp of the output dtype AT the value `scale` (= max|o|): 2^(floor(log2 scale) - 7) for bf16, - 10 for fp16.  (A fixed fraction of
+    max|o| is wrong on one side: 2^-8 max|o| is half an ulp just above a power of two -- seed 425 of a 2000-seed run, one bf16 output one ulp
+    off at 0.61 -- and 2^-7 max|o| is two ulps just below one.)"""
+    import math
+    if not scale > 0.0:
+        return 0.0
+    return 2.0 ** (math.floor(math.log2(scale)) - (7 if dtype_code == 1 else 10))
+
+
 def cos_sim(a: np.ndarray, b: np.ndarray) -> float:
     a = a.astype(np.float64).ravel()
     b = b.astype(np.float64).ravel()
