@@ -7,7 +7,8 @@ copies of those results up to just behind the asm statement.  Round 5 found such
 hoisted above its nops in the causal D = 128 instantiations only; wrong rows in the last query block of lengths with an odd number of
 pipelined tiles).  This script walks the compiler's listing of a unit and reports every instruction that touches the destination of an
 asm-issued MFMA fewer wait states behind it than the ISA's XDL -> VALU rule asks (8-pass MFMA: 11, 16-pass: 19), except another MFMA
-accumulating into the very same registers.  Back-to-back MFMAs are modelled as the matrix pipe issues them (one per `passes` issue
+accumulating into the very same registers; and every non-transcendental instruction that reads the result of an asm-issued
+transcendental (v_exp_f32 ...) in the very next issue slot.  Back-to-back MFMAs are modelled as the matrix pipe issues them (one per `passes` issue
 slots: the wait in front of the second one counts for the first).  It follows the listing and, where MFMAs are still pending at a branch, the branch target too.
 
     python tools/mfma_hazard_lint.py [unit.hip ...]        (default: the six attention units)"""
@@ -27,6 +28,7 @@ NEED = {"v_mfma_f32_32x32x64_f8f6f4": 19, "v_mfma_scale_f32_32x32x64_f8f6f4": 19
 NEED_DEFAULT = 11
 PASSES = {k: 16 for k in NEED}
 PASSES_DEFAULT = 8
+TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")      # their result needs one issue slot before a non-transcendental VALU reads it
 TAKEN_BRANCH = 2           # issue slots a taken branch costs on top of its own (assumed: the instruction buffer refills; >= 8 clocks)
 _REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -80,6 +82,7 @@ def _walk(ins, labels, start, pending, findings, top):
     a fork only carries the MFMAs pending at its branch and ends when their windows have passed.  -> number of asm MFMAs seen"""
     n_mfma, kernel = 0, ins[start][0] if start < len(ins) else "?"
     busy = 0                   # passes the matrix pipe is still occupied for: an MFMA issued inside them waits for the remainder
+    trans = None               # (register, text) of an asm-issued transcendental in the previous issue slot
     for idx in range(start, len(ins)):
         k, ln, line, op, ops, in_asm = ins[idx]
         if k != kernel:
@@ -94,8 +97,16 @@ def _walk(ins, labels, start, pending, findings, top):
                 _walk(ins, labels, labels[ops[0]], [[p[0], p[1], p[2] - states - TAKEN_BRANCH, p[3]] for p in pending], findings, False)
                 if op == "s_branch":
                     pending = []
+            trans = None
         else:
             is_mfma = op.startswith("v_mfma")
+            if trans is not None and not op.startswith(TRANS) and top:
+                for o in ops[1:] if op.startswith("v_") else ops:
+                    if any(a <= trans[0] <= b for a, b in _regs(o)):
+                        findings.add((kernel, ln, line, trans[1], 1))
+            trans = None
+            if in_asm and op.startswith(TRANS) and ops and _regs(ops[0]):
+                trans = (_regs(ops[0])[0][0], line)
             for lo, hi, need, what in pending:
                 if need <= 0:
                     continue
