@@ -442,13 +442,16 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                 }
                 for (int i = 0; i < rows; i++) {
                     uint16_t *orow = o + ((size_t)(b * Hq + h) * Lq + r0 + i) * D;
+                    /* a row of a query block whose every tile was skipped (bool mask, all-False blocks): the Triton kernel's l_i starts at 1.0
+                     * and nothing multiplies it (attn_qk_int8_per_block.py:111-112,122), so o = 0 / 1 = 0; its lse is log2(1) + (-inf) (:127) */
+                    const float li = (l[i] == 0.0f && m[i] == NEG_BIG) ? 1.0f : l[i];
                     for (int d = 0; d < D; d++) {
-                        float x = acc[i][d] / l[i];
+                        float x = acc[i][d] / li;
                         if (fp8) x *= v_scale[(size_t)(b * Hkv + hk) * D + d];
                         if (v_mean) x += v_mean[(size_t)(b * Hkv + hk) * D + d];   /* sm89.cuh:575-621 */
                         orow[d] = st16(x, out_dtype);
                     }
-                    if (lse) lse[(size_t)(b * Hq + h) * Lq + r0 + i] = log2f(l[i]) + m[i];
+                    if (lse) lse[(size_t)(b * Hq + h) * Lq + r0 + i] = (l[i] == 0.0f && m[i] == NEG_BIG) ? -INFINITY : log2f(l[i]) + m[i];
                 }
                 free(acc);
                 free(p);

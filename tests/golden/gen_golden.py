@@ -138,11 +138,15 @@ def mask_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, kind, seed=0):
         mask[:, :, 130:140, :] = False              # fully masked rows
         mask[:, :, :, 0] |= torch.rand(B, 1, Lq) > 0.1
         mask[:, :, 130:140, :] = False
+    elif kind == "bool_skipall":                    # the whole first query block sees no key: EVERY tile of it is skipped (o = 0 / l_i's initial 1.0, lse = -inf)
+        mask = torch.rand(B, 1, Lq, Lk) > 0.4
+        mask[:, :, :128, :] = False
+        mask[:, :, 131, :] = False                  # and one fully masked row inside a block that does run
     else:
         mask = (2.0 * torch.randn(1, Hq, Lq, Lk)).to(dtype)
         mask[:, :, :, 5:9] = -30000.0
     o, lse, aux = ref_dense(q, k, v, False, attn_mask=mask)
-    m = mask.numpy() if kind == "bool" else bits(mask)
+    m = mask.numpy() if kind.startswith("bool") else bits(mask)
     save(name, q=bits(q), k=bits(k), v=bits(v), o=bits(o), lse=lse.numpy(), mask=m,
          meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64))
 
@@ -198,6 +202,9 @@ if __name__ == "__main__":
         mask_case("mask_bool_lq300_lk333_d64_f16", 2, 4, 2, 300, 333, 64, f16, "bool", seed=8)
         mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--mask-skipall-only":
+        mask_case("mask_bool_skipall_lq140_lk130_d64_f16", 1, 2, 1, 140, 130, 64, f16, "bool_skipall", seed=12)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--varlen-cross-only":
         varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
         varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
@@ -215,3 +222,4 @@ if __name__ == "__main__":
     mask_case("mask_add_lq200_lk256_d128_bf16", 1, 2, 2, 200, 256, 128, bf16, "add", seed=9)
     varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
     varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
+    mask_case("mask_bool_skipall_lq140_lk130_d64_f16", 1, 2, 1, 140, 130, 64, f16, "bool_skipall", seed=12)

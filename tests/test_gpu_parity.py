@@ -451,7 +451,8 @@ def test_triton_api_vs_reference_golden(name, layout):
         assert (qs.cpu().numpy() == z["q_scale"]).all() and (ks.cpu().numpy() == z["k_scale"]).all()
 
 
-@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add")])
+@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add"),
+                                       ("mask_bool_skipall_lq140_lk130_d64_f16", "bool")])
 @pytest.mark.parametrize("layout", ["HND", "NHD"])
 def test_attn_mask_vs_reference_golden(name, kind, layout):
     """sageattn_qk_int8_pv_fp16_triton(attn_mask=...) against the reference Triton kernel's output, incl. the
@@ -468,7 +469,10 @@ def test_attn_mask_vs_reference_golden(name, kind, layout):
     assert np.isfinite(got).all()
     assert err <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
     # fully masked rows carry an LSE of about -1e6/log2e where one fp32 ulp is 0.0625
-    assert (np.abs(lse.cpu().numpy() - z["lse"]) <= 2e-2 + 2e-7 * np.abs(z["lse"])).all()
+    # (skipall: a query block whose every tile is skipped -- rows of zeros with an lse of -inf, in the reference and here)
+    lse, fin = lse.cpu().numpy(), np.isfinite(z["lse"])
+    assert np.array_equal(np.isneginf(lse), ~fin)
+    assert (np.abs(lse[fin] - z["lse"][fin]) <= 2e-2 + 2e-7 * np.abs(z["lse"][fin])).all()
     with pytest.raises(AssertionError):
         sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout=layout, attn_mask=mask, is_causal=True)
 
@@ -684,7 +688,7 @@ def _assert_vs_oracle(tag, got, ref_bits, dt, tol_rel=2e-3):
     assert np.isfinite(got).all()
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max())
-    rms = float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+    rms = float(np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30))
     REPORT[f"full_vs_oracle/{tag}"] = dict(max_abs=err, max_o=scale, rel_rms=rms, elements=int(ref.size))
     assert err <= tol_rel * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale, f"{tag}: max|diff| {err:.3e} vs max|o| {scale:.3e}"
 
@@ -1075,10 +1079,10 @@ def test_causal_ragged_last_block_with_an_odd_count_of_pipelined_tiles(oracle_mo
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))
 def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     """The seeded sweep above for the entry points it does not reach: the Triton-named API (per-block scales, Q quantised in the kernel),
-    sageattn_varlen (packed sequences of random lengths incl. 1-token and empty-query ones, cu_q != cu_k when not causal), and the sm90 entry
-    point (its own scale groups) -- each against the oracle on identical operands with the same K mean."""
+    sageattn_varlen (packed sequences of random lengths incl. 1-token and empty-query ones, cu_q != cu_k when not causal), the sm90 entry
+    point (its own scale groups) and attn_mask (bool / additive, broadcast shapes) -- each against the oracle on identical operands with the same K mean."""
     rng = np.random.default_rng(5000 + seed)
-    kind = ("triton", "varlen", "sm90")[seed % 3]
+    kind = ("triton", "varlen", "sm90", "mask")[seed % 4]
     D = int(rng.choice([64, 128]))
     Hkv = int(rng.integers(1, 4))
     Hq = Hkv * int(rng.choice([1, 2, 4]))
@@ -1107,11 +1111,37 @@ def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
         return
     B = int(rng.integers(1, 3))
     Lk = pick_len()
+    if kind == "mask":
+        causal = False                                   # (core.py:310: no mask under is_causal)
     Lq = Lk if (causal and (kind == "triton" or rng.random() < 0.7)) else int(rng.integers(1, 420))
     layout = str(rng.choice(["HND", "NHD"]))
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
     km = util.bits(sq.channel_mean(k.to(DEV)))
     desc = f"{kind} B{B} Hq{Hq} Hkv{Hkv} Lq{Lq} Lk{Lk} D{D} dt{dt} causal{causal} {layout}"
+    if kind == "mask":
+        # bool (with all-False 128 x 64 tiles, which the kernel skips, and fully masked rows) or additive in q's dtype; broadcast over batch / heads at random
+        mshape = (B if rng.random() < 0.5 else 1, Hq if rng.random() < 0.5 else 1, Lq, Lk)
+        g = torch.Generator().manual_seed(seed + 9)
+        if rng.random() < 0.5:
+            m = torch.rand(mshape, generator=g) < 0.7
+            m[..., : min(Lq, 130), 64:192] = False
+            m[..., Lq // 2, :] = False
+            kw = dict(mask_bool=m.numpy())
+        else:
+            m = (2.0 * torch.randn(mshape, generator=g)).to(T(dt))
+            kw = dict(mask_add=util.f32(util.bits(m), dt))
+        desc += f" mask {tuple(mshape)} {m.dtype}"
+        ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, pv="f16_triton", qk_quant_gran="per_block",
+                                                    return_lse=True, km=km, **kw)
+        o, lse = sa.sageattn_qk_int8_pv_fp16_triton(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout,
+                                                    attn_mask=m.to(DEV), return_lse=True)
+        torch.cuda.synchronize()
+        _assert_vs_oracle(f"random/{seed}/{desc}", to_hnd(o, layout).float().cpu().numpy(), ref, dt)
+        # (fully masked rows carry an LSE of about -1e6 / log2 e, where one fp32 ulp is 0.0625)
+        lse, fin = lse.cpu().numpy(), np.isfinite(lse_ref)
+        assert np.array_equal(np.isneginf(lse), ~fin), desc              # (a query block with every tile skipped: zeros, lse -inf)
+        assert (np.abs(lse[fin] - lse_ref[fin]) <= (5e-3 if dt == 0 else 2e-2) + 2e-7 * np.abs(lse_ref[fin])).all(), desc
+        return
     if kind == "triton":
         ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
                                                     qk_quant_gran="per_block", return_lse=True, km=km)

@@ -62,16 +62,20 @@ def test_varlen_cu_q_differs_from_cu_k_matches_reference(oracle_mod, name):
     assert np.abs(of - rf).max() <= tol
 
 
-@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add")])
+@pytest.mark.parametrize("name,kind", [("mask_bool_lq300_lk333_d64_f16", "bool"), ("mask_add_lq200_lk256_d128_bf16", "add"),
+                                       ("mask_bool_skipall_lq140_lk130_d64_f16", "bool")])
 def test_attn_mask_matches_reference(oracle_mod, name, kind):
-    """Triton API attn_mask semantics (bool 0/-1e6 + all-False tile skip, additive float), incl. fully masked rows."""
+    """Triton API attn_mask semantics (bool 0/-1e6 + all-False tile skip, additive float), incl. fully masked rows -- and (skipall) a query block
+    whose EVERY tile is skipped: the reference's l_i starts at 1.0 (attn_qk_int8_per_block.py:112), so its rows are 0 with an lse of -inf."""
     z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden(name)
     kw = dict(mask_bool=z["mask"]) if kind == "bool" else dict(mask_add=util.f32(z["mask"], dt))
     o, lse, _ = oracle_mod.sageattn_dense(z["q"], z["k"], z["v"], dt, pv="f16_triton", return_lse=True, **kw)
     of, rf = util.f32(o, dt), util.f32(z["o"], dt)
     tol = (2 ** -10 if dt == 0 else 2 ** -7) * max(1.0, float(np.abs(rf).max()))
     assert np.abs(of - rf).max() <= tol
-    assert np.abs(lse - z["lse"]).max() < 1e-4
+    fin = np.isfinite(z["lse"])
+    assert np.array_equal(np.isneginf(lse), np.isneginf(z["lse"])) and (name.find("skipall") < 0 or (~fin).sum() == B * Hq * 128)
+    assert np.abs(lse[fin] - z["lse"][fin]).max() < 1e-4
 
 
 def test_per_thread_quant_matches_reference(oracle_mod):
