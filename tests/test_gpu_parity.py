@@ -81,8 +81,11 @@ def to_hnd(t, layout):
 @pytest.mark.parametrize("gran", ["per_block_triton", "per_block_cuda", "per_warp32", "per_warp16", "per_thread"])
 @pytest.mark.parametrize("dt,D,layout", [(0, 128, "HND"), (1, 64, "NHD"), (0, 64, "HND"), (1, 128, "NHD")])
 def test_quant_int8_bit_exact(oracle_mod, gran, dt, D, layout):
-    B, Hq, Hkv, Lq, Lk = 2, 4, 2, 300, 333
-    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=1, kbias=2.0)
+    _check_quant_int8(oracle_mod, gran, dt, D, layout, 2, 4, 2, 300, 333, seed=1, kbias=2.0)
+
+
+def _check_quant_int8(oracle_mod, gran, dt, D, layout, B, Hq, Hkv, Lq, Lk, seed, kbias):
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=kbias)
     km = k.float().mean(dim=2).to(T(dt))                                   # [B,Hkv,D]
     qd, kd = to_dev(q, layout), to_dev(k, layout)
     kmd = km.to(DEV).unsqueeze(2 if layout == "HND" else 1)
@@ -112,6 +115,24 @@ def test_quant_int8_bit_exact(oracle_mod, gran, dt, D, layout):
     for name, a, b in zip(("q_int8", "q_scale", "k_int8", "k_scale"), got, (rq8, rqs, rk8, rks)):
         assert a.shape == b.shape, name
         assert (a == b).all(), f"{name}: {(a != b).sum()} mismatches of {a.size}"
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))
+def test_random_operands_bit_exact_vs_oracle(oracle_mod, seed):
+    """Seeded random shapes through the operand kernels: INT8 Q / K and their scales (every granularity and rounding style), the FP8 V image
+    and its per-channel scales, the FP16 V image -- every byte against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.choice([64, 128]))
+    Hkv = int(rng.integers(1, 4))
+    Hq = Hkv * int(rng.choice([1, 2, 4]))
+    B = int(rng.integers(1, 3))
+    pick_len = lambda: int(rng.choice([int(rng.integers(1, 200)), int(rng.integers(190, 330)), int(rng.integers(500, 1500))]))
+    Lq, Lk = pick_len(), pick_len()
+    dt = int(rng.integers(0, 2))
+    layout = str(rng.choice(["HND", "NHD"]))
+    gran = str(rng.choice(["per_block_triton", "per_block_cuda", "per_warp32", "per_warp16", "per_thread"]))
+    _check_quant_int8(oracle_mod, gran, dt, D, layout, B, Hq, Hkv, Lq, Lk, seed=seed, kbias=float(3 * rng.random()))
+    _check_v_images(oracle_mod, dt, D, layout, Lk, B, Hkv, seed=seed)
 
 
 @pytest.mark.parametrize("style", ["triton", "thread"])
@@ -155,8 +176,11 @@ def test_quant_golden_per_thread(oracle_mod):
 
 @pytest.mark.parametrize("dt,D,layout,L", [(0, 128, "HND", 300), (1, 64, "NHD", 64), (1, 128, "HND", 1000), (0, 64, "NHD", 129)])
 def test_prep_v_images_bit_exact(oracle_mod, dt, D, layout, L):
-    B, H = 2, 3
-    g = torch.Generator().manual_seed(5)
+    _check_v_images(oracle_mod, dt, D, layout, L, 2, 3, seed=5)
+
+
+def _check_v_images(oracle_mod, dt, D, layout, L, B, H, seed):
+    g = torch.Generator().manual_seed(seed)
     v = (torch.randn(B, H, L, D, generator=g) * (1 + 3 * torch.rand(1, H, 1, D, generator=g))).to(T(dt))
     vd = to_dev(v, layout)
     img8, vs, _ = sq.per_channel_fp8(vd, tensor_layout=layout)

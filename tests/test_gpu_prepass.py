@@ -78,6 +78,25 @@ def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth
     assert int(sync.abs().sum().item()) == 0           # counters re-armed by the kernel, no give-up flag
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SAGE_RANDOM_SEEDS", "24")))))
+def test_random_shapes_fused_prepass_bit_equals_the_sequence(seed):
+    """Seeded random shapes (lengths around the 16-token, 64-key and 512-token slab edges, up to a dozen slabs) of the comparison above."""
+    rng = np.random.default_rng(7000 + seed)
+    B, H = int(rng.integers(1, 4)), int(rng.integers(1, 7))
+    L = int(rng.choice([int(rng.integers(1, 130)), int(rng.integers(500, 530)), int(rng.integers(1000, 1100)), int(rng.integers(1, 6200))]))
+    D = int(rng.choice([64, 128]))
+    dtype = (torch.float16, torch.bfloat16)[int(rng.integers(0, 2))]
+    layout = str(rng.choice(["HND", "NHD"]))
+    smooth_k, smooth_v = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    gran = str(rng.choice(["per_thread", "per_warp", "per_block_triton"]))
+    blkk = 64 if gran == "per_block_triton" else int(rng.choice([64, 128]))
+    k, v = _mk(B, H, L, D, dtype, layout, seed)
+    ref = _sequence(k, v, layout, smooth_k, smooth_v, blkk, gran)
+    got = quant.prepass_kv_fp8(k, v, layout, smooth_k=smooth_k, smooth_v=smooth_v, BLKK=blkk, qk_quant_gran=gran)
+    for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+        _same(a, b, f"{name}: B{B} H{H} L{L} D{D} {dtype} {layout} smooth_k{smooth_k} smooth_v{smooth_v} blkk{blkk} {gran}")
+
+
 def test_triton_api_one_launch_prepass_is_bit_identical():
     """sageattn_qk_int8_pv_fp16_triton through the one-launch pre-pass (K mean + Triton-rounded per-block INT8 K + fp16 V image) against the
     kernel sequence, incl. an all-zero K block (scale 0 -> INT8 zeros, as the stand-alone quantiser gives) and the masked kernels."""
