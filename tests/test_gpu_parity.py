@@ -1106,8 +1106,8 @@ def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     sageattn_varlen (packed sequences of random lengths incl. 1-token and empty-query ones, cu_q != cu_k when not causal), the sm90 entry
     point (its own scale groups) and attn_mask (bool / additive, broadcast shapes) -- each against the oracle on identical operands with the same K mean."""
     rng = np.random.default_rng(5000 + seed)
-    kind = ("triton", "varlen", "sm90", "mask")[seed % 4]
-    D = int(rng.choice([64, 128]))
+    kind = ("triton", "varlen", "sm90", "mask", "pad")[seed % 5]
+    D = int(rng.choice([64, 128])) if kind != "pad" else int(rng.choice([8, 40, 56, 72, 80, 96, 100, 120]))    # (pad: sageattn() with other head sizes)
     Hkv = int(rng.integers(1, 4))
     Hq = Hkv * int(rng.choice([1, 2, 4]))
     dt = int(rng.integers(0, 2))
@@ -1140,7 +1140,8 @@ def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     Lq = Lk if (causal and (kind == "triton" or rng.random() < 0.7)) else int(rng.integers(1, 420))
     layout = str(rng.choice(["HND", "NHD"]))
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
-    km = util.bits(sq.channel_mean(k.to(DEV)))
+    Dp = D if kind != "pad" else (64 if D <= 64 else 128)          # (the K mean of a padded call is taken over the padded tensor: zeros in the pad)
+    km = util.bits(sq.channel_mean(torch.nn.functional.pad(k, (0, Dp - D)).to(DEV)))
     desc = f"{kind} B{B} Hq{Hq} Hkv{Hkv} Lq{Lq} Lk{Lk} D{D} dt{dt} causal{causal} {layout}"
     if kind == "mask":
         # bool (with all-False 128 x 64 tiles, which the kernel skips, and fully masked rows) or additive in q's dtype; broadcast over batch / heads at random
@@ -1166,7 +1167,22 @@ def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
         assert np.array_equal(np.isneginf(lse), ~fin), desc              # (a query block with every tile skipped: zeros, lse -inf)
         assert (np.abs(lse[fin] - lse_ref[fin]) <= (5e-3 if dt == 0 else 2e-2) + 2e-7 * np.abs(lse_ref[fin])).all(), desc
         return
-    if kind == "triton":
+    if kind == "pad":
+        # sageattn(): head sizes padded to 64 / 128 (core.py:253-268 -> FP8 two-level, per-thread on this device), softmax scale of the ORIGINAL size
+        # unless given, K smoothing optional
+        smooth_k = bool(rng.random() < 0.7)
+        sm_scale = None if rng.random() < 0.6 else float(0.05 + 0.2 * rng.random())
+        desc += f" smooth_k{smooth_k} sm_scale{sm_scale}"
+        ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8", qk_quant_gran="per_thread",
+                                                    return_lse=True, km=km if smooth_k else None, smooth_k=smooth_k, sm_scale=sm_scale, fp8_scores=SCORES)
+        if smooth_k:
+            o, lse = sa.sageattn(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout, is_causal=causal, sm_scale=sm_scale,
+                                 return_lse=True)
+        else:
+            o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout, is_causal=causal,
+                                                     sm_scale=sm_scale, smooth_k=False, pv_accum_dtype="fp32+fp32", return_lse=True)
+        assert o.shape[-1] == D
+    elif kind == "triton":
         ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
                                                     qk_quant_gran="per_block", return_lse=True, km=km)
         o, lse = sa.sageattn_qk_int8_pv_fp16_triton(to_dev(q, layout), to_dev(k, layout), to_dev(v, layout), tensor_layout=layout,
