@@ -13,7 +13,7 @@ call1() {   # the ABI-19 / folded-score build: suite, bench line, then the causa
     echo "probe $c rc $?"; grep -v amdgpu.ids $out/probe_$c.log | tail -6
   done
 }
-call2() {   # suite, pre-pass / attention overlap probe, bench line, then ROUND 4's tree (variants/r4tree = git worktree of 2844541, patched as
+call2() {   # suite, pre-pass / attention overlap probe, bench line, then ROUND 4's tree (variants/r4tree = a scratch git worktree of 2844541 -- removed at the end of the round --, patched as
             # profiles/r5_pers_causal_probe.txt says) with its ticket loop in the causal kernels
   out=gpurun_out/r5b; mkdir -p $out; suite ""
   for c in c2 c3; do timeout 200 python tools/overlap_probe.py $c 20 2>&1 | grep -v amdgpu.ids | tee $out/overlap_$c.txt; done
