@@ -317,6 +317,8 @@ def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     buf = _SYNC_CACHE.get(key)
     if buf is None or buf.numel() < words:
+        if buf is None and len(_SYNC_CACHE) >= 64:         # streams come and go: the oldest entry leaves (its memory goes back to the caching
+            _SYNC_CACHE.pop(next(iter(_SYNC_CACHE)))       # allocator in the order of the stream it was allocated on, i.e. behind its last launch)
         buf = _SYNC_CACHE[key] = torch.zeros((max(words, 4096),), dtype=torch.int32, device=device)
     return buf
 

@@ -97,6 +97,27 @@ def test_random_shapes_fused_prepass_bit_equals_the_sequence(seed):
         _same(a, b, f"{name}: B{B} H{H} L{L} D{D} {dtype} {layout} smooth_k{smooth_k} smooth_v{smooth_v} blkk{blkk} {gran}")
 
 
+def test_the_per_stream_sync_buffers_are_bounded():
+    """quant._prepass_sync keeps one zeroed counter buffer per (device, stream); the table is bounded (streams come and go)."""
+    k, v = _mk(1, 2, 700, 64, torch.float16, "HND", 3)
+    ref = quant.prepass_kv_fp8(k, v, "HND")
+    saved = dict(quant._SYNC_CACHE)
+    try:
+        for i in range(64):
+            quant._SYNC_CACHE[(0, -1 - i)] = torch.zeros((4096,), dtype=torch.int32, device="cuda")
+        full = len(quant._SYNC_CACHE)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            got = quant.prepass_kv_fp8(k, v, "HND")
+        s.synchronize()
+        assert full >= 64 and len(quant._SYNC_CACHE) <= full            # the new stream's buffer displaced the oldest entry
+        for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
+            _same(a, b, name)
+    finally:
+        quant._SYNC_CACHE.clear()
+        quant._SYNC_CACHE.update(saved)
+
+
 def test_triton_api_one_launch_prepass_is_bit_identical():
     """sageattn_qk_int8_pv_fp16_triton through the one-launch pre-pass (K mean + Triton-rounded per-block INT8 K + fp16 V image) against the
     kernel sequence, incl. an all-zero K block (scale 0 -> INT8 zeros, as the stand-alone quantiser gives) and the masked kernels."""
