@@ -1,4 +1,4 @@
-"""Soak of the hand-scheduled kernels (GPU): the steady-state loops of csrc/sage_attn.hip pin their
+"""Soak of the hand-scheduled kernels (GPU): the steady-state loops of csrc/sage_attn_kernel.h pin their
 instruction order in asm and manage their own hazards and LDS ring, so a missed hazard or a race shows up as a lane-, wave- or
 tile-sized difference between two identical calls, rarely (round 2 shipped one that appeared once in a few hundred launches).
 

@@ -144,7 +144,7 @@ def test_c4_work_list_shape():
 
 
 def test_ticket_queues_of_the_persistent_launch_partition_the_logical_grid():
-    """The persistent launch (csrc/sage_attn.hip, `PERS_OK` kernels) deals the logical workgroup indices 0 .. nwg - 1 into 32 queues: index
+    """The persistent launch (csrc/sage_attn_kernel.h, `PERS_OK` kernels) deals the logical workgroup indices 0 .. nwg - 1 into 32 queues: index
     i = 32 k + 8 s + x belongs to XCD x = i & 7 (the work order's locality) and sub-queue s = (i >> 3) & 3, ticket k.  Restated here: the queues
     partition the grid for every nwg (also one that is no multiple of 32), the count formula the kernel uses for "how much is left" is the size
     of the queue, and the first round -- a launch of G workgroups, G a multiple of 32, takes i = blockIdx.x without a ticket -- is exactly the
