@@ -119,6 +119,10 @@
 
 namespace sage {
 
+// hwreg(HW_REG_MODE, 23, 1): the FP16_OVFL bit of the MODE register (id 1 | offset 23 << 6 | (width 1 - 1) << 11)
+constexpr int kHwregModeFp16Ovfl = 1 | (23 << 6) | (0 << 11);
+
+
 template <int D, bool PV_FP8, int NH> struct TileCfg {
     static constexpr int KT = BLKK * NH;                        // keys per iteration
     static constexpr int K_TILE_BYTES = KT * D;                 // int8
@@ -290,6 +294,13 @@ sage_attn_kernel(const AttnParams p_arg)
     int n = lane & 31;            // query row inside the wave's 32-row tile
     int g = lane >> 5;            // k-group (operand half)
     SAGE_TSTAMP(0);
+    // Inside the key loop the conversions of P saturate to the largest finite value instead of overflowing (MODE.FP16_OVFL = 1; back to 0 in front
+    // of the epilogue, whose output conversion overflows to inf as the reference's does).  FP8 PV: the reference converts P with
+    // cvt.rn.satfinite.e4m3x2.f32 (numeric_conversion.cuh:46-61) and v_cvt_pk_fp8_f32 without the mode bit returns NaN above 464.  With the exact
+    // score form P exceeds 448 = 2^8.807 only by the rounding of m (scores of millions); the folded form's m + bias c' is rounded at a magnitude
+    // of bias c', so from c = sm_scale log2(e) q_scale k_scale ~ 0.1 (|q|, |k| ~ 100) on a row's largest P can pass 464 -- NaN rows without this.
+    // FP16 PV: the folded bias of the pipelined loops likewise, at c ~ 50, against fp16's 65504.
+    __builtin_amdgcn_s_setreg(kHwregModeFp16Ovfl, 1);
 
     // ---- work item: XCD-aware, heavy-first --------------------------------------------------
     const int nqblk = p.nqblk;
@@ -1581,6 +1592,7 @@ sage_attn_kernel(const AttnParams p_arg)
     }
 
     // ---- epilogue: normalise, (x v_scale, + v_mean), cast, transpose through LDS, store rows ----
+    __builtin_amdgcn_s_setreg(kHwregModeFp16Ovfl, 0);
     const float l_tot = pair_sum(l_run);
     const float inv = l_tot > 0.0f ? __builtin_amdgcn_rcpf(l_tot) : 0.0f;
     if (p.lse != nullptr && g == 0 && my_row < Lq) {

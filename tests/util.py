@@ -85,7 +85,7 @@ def out_ulp(scale: float, dtype_code: int) -> float:
     import math
     if not scale > 0.0:
         return 0.0
-    return 2.0 ** (math.floor(math.log2(scale)) - (7 if dtype_code == 1 else 10))
+    return max(2.0 ** (math.floor(math.log2(scale)) - (7 if dtype_code == 1 else 10)), 2.0 ** -24 if dtype_code == 0 else 0.0)   # (fp16 subnormals: 2^-24 apart)
 
 
 def cos_sim(a: np.ndarray, b: np.ndarray) -> float:
