@@ -305,7 +305,11 @@ typedef struct SageLaunchAttr {
  * m + bias * c' rounded once per (row, 64-key tile, k scale) -- up to 0.64 of one INT8 x INT8 score step of error in the exponent, which
  * re-rolls a few e4m3 roundings of P per row (statistically the same result; measured against the exact form: DESIGN.md 4).  With this
  * flag ("exact"): the bias is subtracted first (exact, Sterbenz), then the FMA -- bit for bit the reference's formula, 3-7 % slower.
- * The oracle has both forms (oracle/sage_oracle.c score_mode); each form is held to 2e-3 * max|o| against its own. */
+ * The oracle has both forms (oracle/sage_oracle.c score_mode); each form is held to 2e-3 * max|o| against its own.
+ * Range: the folded form rounds m + bias c' at the magnitude of bias c', an error of up to 0.32 c in the exponent of a (row, tile, k scale) group,
+ * c = sm_scale log2(e) q_scale k_scale = the exponent change per INT8 x INT8 score step (1e-4 ... 1e-2 on ordinary inputs).  It is meant for c << 0.1;
+ * inputs with |q|, |k| in the hundreds (c >= 0.1) should take the exact form.  Either way P saturates like the reference's cvt.rn.satfinite (no NaN;
+ * profiles/r5_run_i_score_scale_range.txt). */
 #define SAGE_ATTR_FP8_EXACT_SCORES 1u
 /* tests: take the persistent route from two rounds of workgroups up instead of twelve (needs launch_ws) */
 #define SAGE_ATTR_FORCE_PERSISTENT 2u

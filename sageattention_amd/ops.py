@@ -43,7 +43,9 @@ _FP8_EXACT = os.environ.get("SAGE_FP8_SCORES", "folded").lower() == "exact"
 
 
 def fp8_exact(kwarg=None) -> bool:
-    """``fp8_scores=`` of the FP8 entry points ("exact" / "folded" / None = the process default, SAGE_FP8_SCORES)."""
+    """``fp8_scores=`` of the FP8 entry points ("exact" / "folded" / None = the process default, SAGE_FP8_SCORES).  "folded" (3-7 % faster) is for
+    ordinary magnitudes -- its rounding error grows with c = sm_scale log2(e) q_scale k_scale, the exponent change per INT8 score step (include/sage_gfx950.h);
+    with |q|, |k| in the hundreds (c >= 0.1) ask for "exact"."""
     if kwarg is None:
         return _FP8_EXACT
     if kwarg not in ("exact", "folded"):
