@@ -38,77 +38,23 @@
 #include <cstdlib>
 #include <type_traits>
 
-// ---- build-time switches used for the A/B ladder in DESIGN.md ------------------------------------
-#ifndef SAGE_GLDS       // K/V tiles by LDS-DMA instead of VGPR staging (+4%)
-#define SAGE_GLDS 1
-#endif
-#ifndef SAGE_MXPV       // FP8 PV on the block-scaled K=64 MFMA with unit scales (+5%)
-#define SAGE_MXPV 1
-#endif
-#ifndef SAGE_KPRELOAD   // steady iteration: request all K fragments before the first QK MFMA
-#define SAGE_KPRELOAD 1
-#endif
-#ifndef SAGE_STEADY     // branch-free steady-state iteration for whole, unmasked tiles
-#define SAGE_STEADY 1
-#endif
-#ifndef SAGE_STAGES     // LDS ring depth: 3 = two tiles in flight, counted vmcnt + raw s_barrier (needs SAGE_GLDS)
-#define SAGE_STAGES 3
-#endif
-#ifndef SAGE_NH_F8      // 64-key images per iteration (2 = 128-key tiles: spills at D=128 today)
-#define SAGE_NH_F8 1
-#endif
-
-#ifndef SAGE_MAGIC      // the int32 QK^T accumulators start from the bit pattern of the inline constant 1/(2 pi) = 0x3E22F983 (free as
-#define SAGE_MAGIC 1    // the MFMA's C operand): read as a float they are 1/(2 pi) + s * 2^-26 exactly, so one exact v_sub_f32 (2 cycles)
-#endif                  // replaces v_cvt_f32_i32 (4) and the 2^26 goes into the scale: bit-identical scores (see sfl below)
-#ifndef SAGE_PIPE       // software-pipelined steady-state iteration (FP8 PV): the PV MFMAs of tile t-1 and the QK^T MFMAs of tile t+1
-#define SAGE_PIPE 1     // are dealt between the softmax VALU groups of tile t, so the matrix work hides under the wave's own VALU stream
-#endif
-#ifndef SAGE_PIPE16     // the software-pipelined steady-state loop for FP16 PV as well
-#define SAGE_PIPE16 1
-#endif
-#ifndef SAGE_PLAIN_PV   // pipelined FP8 loop: v_mfma_f32_32x32x64_f8f6f4 instead of its block-scaled form with unit scales
-#define SAGE_PLAIN_PV 1
-#endif
-#ifndef SAGE_GRP4       // experiment: the FP8 pipelined loop's softmax in statements of four scores
-#define SAGE_GRP4 1
-#endif
-#ifndef SAGE_RSUM_MFMA   // experiment: FP16-PV CUDA form, pipelined loop: the row sum of the fp16-rounded P from the matrix pipe (a ones
-#define SAGE_RSUM_MFMA 0 // fragment against P, the reference's mma::rowsum_f16f16f32) instead of two v_fma_mix_f32 per score pair
-#endif
-#ifndef SAGE_ATTN_TRACE      // experiment (tools/attn_trace.py): wave 0 of every workgroup records 100 MHz time stamps of its phases
+// ---- build-time switches --------------------------------------------------------------------------
+// Rounds 1-5 carried an A/B ladder of ~20 switches here (SAGE_GLDS, SAGE_MXPV, SAGE_KPRELOAD, SAGE_STEADY, SAGE_STAGES, SAGE_NH_F8, SAGE_MAGIC,
+// SAGE_PIPE, SAGE_PIPE16, SAGE_PLAIN_PV, SAGE_GRP4, SAGE_RSUM_MFMA, SAGE_FOLDBIAS, SAGE_DIRECT, SAGE_PERS_QF, SAGE_PERS_CAUSAL); every one is
+// folded to the value that shipped and its alternative body deleted (round 6).  The last tree that still builds them:
+// `git show b0d43f7:sageattention_amd/csrc/sage_attn_kernel.h`; what each measured is in DESIGN.md 3.1 / 3.7 / 3.8.  What is fixed now: K / V tiles
+// by LDS-DMA into a 3-slot ring; 64-key iterations; the INT32 QK^T accumulators start from the bit pattern of the inline constant
+// 1 / (2 pi) = 0x3E22F983 (free as the MFMA's C operand), so read as a float they are 1 / (2 pi) + s * 2^-26 exactly and one exact v_add_f32
+// replaces v_cvt_f32_i32; software-pipelined steady-state loops for FP8 and FP16 PV with their instruction order pinned in asm; FP8 PV on
+// v_mfma_f32_32x32x64_f8f6f4; two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only where a row maximum of
+// the wave moved; the ticket loop in the non-causal kernels and in the packed route's causal ones.
+#ifndef SAGE_ATTN_TRACE      // tools/attn_trace.py: wave 0 of every workgroup records 100 MHz time stamps of its phases
 #define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
 #endif
-#ifndef SAGE_ORDER_DEFAULT   // causal work order: -1 = grouped / folded (set_work_order), 0 = head-major heavy-first, n = groups of n heads
-#define SAGE_ORDER_DEFAULT -1
-#endif
-#ifndef SAGE_FOLDBIAS   // FP16-PV pipelined loops: the bias of the score's bit pattern (SAGE_MAGIC) is removed inside the scale FMA,
-#define SAGE_FOLDBIAS 1 // exp2(fma(bits, c, -(m + bias * c))), instead of by a v_add_f32 of its own per score (32 VALU instructions of ~195
-#endif                  // per wave-tile).  m + bias * c is rounded once per (row, tile, k scale): an error of up to 0.64 of ONE integer step
-                        // of the INT8 x INT8 score in the exponent (2^-24 * 0.159 * 2^26 * dequantisation scale ~ 1e-4 on randn inputs), against
-                        // a quantisation noise of ~ 10^2 steps.  With FP16 PV P is rounded to fp16 and the perturbation stays far below the
-                        // parity bar (every oracle test green): 1 = folded (shipped since round 4), 0 = the separate, exact subtraction.
-                        // FP8 PV: BOTH forms are in the library, as the kernel template argument SFOLD (round 5).  The folded form is the
-                        // default (+2.5 % at C3, +6.7 % at C5, profiles/r4_run_b_foldbias_ab.txt) and applies to EVERY tile of an FP8 launch,
-                        // pipelined or not, so the oracle's `score_mode = folded` mirrors it rounding for rounding (oracle/sage_oracle.c) and
-                        // the 2e-3 * max|o| gate is kept against that mode; SAGE_ATTR_FP8_EXACT_SCORES selects the exact form of rounds 1-4,
-                        // which stays the one pinned to the reference's formula exp2(fma(s, c, -m)) (attn_utils.cuh:445-449).
-#ifndef SAGE_PERS_QF      // 0: A/B build without the ticket loop in the causal kernels of the packed route (QF 3 / 4)
-#define SAGE_PERS_QF 1
-#endif
-#ifndef SAGE_PERS_CAUSAL  // experiment (tools/pers_causal_probe.py): the persistent ticket loop compiled into the causal instantiations as well
-#define SAGE_PERS_CAUSAL 0
-#endif
-#ifndef SAGE_DIRECT     // two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only on tiles where a
-#define SAGE_DIRECT 1   // row maximum of the wave moved; 0 = explicit fold O = O * alpha + T per tile
-#endif
 
-#ifndef SAGE_MIN_WAVES  // __launch_bounds__ waves/SIMD the register allocator must allow.  The software-pipelined FP8 loop carries two
-                        // score tiles at D=128 (248 VGPRs: 2 waves; measured equal to 3 waves for the phased loop); D=64 fits 3 (167).
-                        // Phased loops: 3 (<= 168 VGPRs, +3.5% measured) wherever that does not spill.
-#define SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK) \
-    ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : ((PV_FP8) ? (((SAGE_PIPE != 0) && (SAGE_MAGIC != 0) && (!(TWO_LEVEL) || (SAGE_DIRECT != 0))) ? 2 : (((TWO_LEVEL) || !(KTHREAD)) ? 3 : 2)) : 2)))
-#endif
+// __launch_bounds__ waves / SIMD the register allocator must allow: the software-pipelined loops carry two score tiles, which at D = 128 is
+// 2 waves (248 VGPRs); D = 64 fits 3 (167); the attn_mask variants 2.
+#define SAGE_MIN_WAVES(D, MASK) ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : 2))
 
 // asm text of the pipelined loops: two scores d0 / d1 from the bit patterns s0 / s1 of the QK^T accumulators, d = score * c - m (operands as
 // asm placeholders).  FOLD: one FMA per score, m already carries the bias of the bit pattern (SAGE_FOLDBIAS); EXACT: the bias is
@@ -130,7 +76,7 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
     static constexpr int V_IMG_BYTES = D * V_ROW_BYTES;
     static constexpr int STAGE_BYTES = K_TILE_BYTES + NH * V_IMG_BYTES;
     static constexpr int O_BYTES = BLKQ * D * 2;
-    static constexpr int NSTAGE = (SAGE_GLDS && SAGE_STAGES == 3) ? 3 : 2;
+    static constexpr int NSTAGE = 3;                            // LDS ring depth: two tiles in flight, counted vmcnt + raw s_barrier
     static constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > O_BYTES) ? NSTAGE * STAGE_BYTES : O_BYTES;
     static constexpr int KSTEPS = D / 32;                       // i8 MFMA k-steps over head dim
     static constexpr int DT = D / 32;                           // 32-wide output d tiles
@@ -143,29 +89,16 @@ __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2
 // 0x3E22F983 lies mid-binade ([0.125, 0.25), ulp 2^-26, mantissa field 2292099): for |s| <= 128 * 128 * 128 = 2097152 the sum
 // stays inside the binade, so bits + s is the float 1/(2 pi) + s * 2^-26, the subtraction below is exact (Sterbenz) and
 // fma(s * 2^-26, c * 2^26, -m) rounds the same real number as fma((float)s, c, -m): bit-identical to the conversion.
-[[maybe_unused]] constexpr int kSInit = SAGE_MAGIC ? 0x3E22F983 : 0;
-constexpr float kSUnit = SAGE_MAGIC ? 67108864.0f : 1.0f;       // 2^26: folded into the score scale
-__device__ __forceinline__ float sfl(int x)
-{
-#if SAGE_MAGIC
-    return __int_as_float(x) - __int_as_float(0x3E22F983);
-#else
-    return (float)x;
-#endif
-}
+constexpr float kSUnit = 67108864.0f;       // 2^26: folded into the score scale
+__device__ __forceinline__ float sfl(int x) { return __int_as_float(x) - __int_as_float(0x3E22F983); }
 // first MFMA of a QK^T accumulation chain: C = kSInit as an inline constant (hipcc materialises an integer splat of
 // 0x3E22F983 in 16 VGPRs instead; the assembler encodes it as inline operand 248).  The builtin MFMAs that follow take the
 // result whole as their C operand (accumulate chain: no wait states, cdna_hip_programming.md 5.7 item 2).
 __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 {
-#if SAGE_MAGIC
     v16i d;
     asm("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(d) : "v"(a), "v"(b));
     return d;
-#else
-    const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, z, 0, 0, 0);
-#endif
 }
 
 #if SAGE_ATTN_TRACE
@@ -186,7 +119,7 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 // CPERS: the persistent ticket loop compiled into a CAUSAL instantiation (the packed route's launches over the work list; non-causal unmasked
 // instantiations always carry it).
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true, bool CPERS = false>
-__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, PV_FP8, KTHREAD, TWO_LEVEL, MASK))
+__global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, MASK))
 sage_attn_kernel(const AttnParams p_arg)
 {
     // The parameter block is read through the kernarg segment pointer, and inside the persistent loop through a copy of that pointer the
@@ -220,7 +153,7 @@ sage_attn_kernel(const AttnParams p_arg)
     // (round 5: the packed / varlen route's CAUSAL launches over the device-built work list take the route too -- +2.2 ... 2.9 % at C4 -- through
     //  instantiations of their own (CPERS); dense causal launches lose 0.1 ... 7.5 % with tickets and the loop's mere presence costs the dense
     //  Triton-API causal kernel 1.3 %, so their instantiations stay without it: profiles/r5_pers_causal_probe.txt, r5_run_c_qf_pers_ab.txt)
-    constexpr bool PERS_OK = (!CAUSAL || CPERS || SAGE_PERS_CAUSAL != 0) && MASK == 0;
+    constexpr bool PERS_OK = (!CAUSAL || CPERS) && MASK == 0;
     const bool pers = PERS_OK && p.sched != nullptr;
     __shared__ int s_ticket[2];                 // (two slots, alternating: a wave may still be reading the previous ticket when wave 0 posts the next)
     int tpar = 0;
@@ -414,7 +347,6 @@ sage_attn_kernel(const AttnParams p_arg)
     const unsigned char *kbase = reinterpret_cast<const unsigned char *>(p.k) + k_off;
     const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v);
     constexpr int CPR = D / 16;                                   // 16-B chunks per K row
-#if SAGE_GLDS
     // LDS-DMA: every wave-instruction moves 64 x 16 B = 1 KiB; the LDS destination is lane-linear
     // (M0 base + lane*16), so the XOR swizzle of the K image goes on the per-lane SOURCE address.
     // Key rows past Lk are clamped to the last valid row, V images past the last one to the last
@@ -429,11 +361,11 @@ sage_attn_kernel(const AttnParams p_arg)
         const int row = e / CPR, phys = e % CPR;
         koff[i] = (unsigned)(row * (int)p.k_sl + swz_chunk<D>(row, phys) * 16);
     }
-    auto issue_loads = [&](auto steady_tag, int it, int buf) {      // steady: tile `it` is known to be a whole tile
+    auto issue_loads = [&](int it, int buf) {
         unsigned char *ks = smem + buf * C::STAGE_BYTES;
         unsigned char *vs = ks + C::K_TILE_BYTES;
         const unsigned char *kt = kbase + (long)it * KT * p.k_sl;
-        if (decltype(steady_tag)::value || it * KT + KT <= Lk) {
+        if (it * KT + KT <= Lk) {
 #pragma unroll
             for (int i = 0; i < KP / 4; i++) {
                 const int pc = wave * (KP / 4) + i;
@@ -456,7 +388,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             int tv = it * NH + hh;
-            if (!decltype(steady_tag)::value) tv = tv < ntk_all ? tv : ntk_all - 1;
+            tv = tv < ntk_all ? tv : ntk_all - 1;
             const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
 #pragma unroll
             for (int i = 0; i < VP / 4; i++) {
@@ -466,44 +398,6 @@ sage_attn_kernel(const AttnParams p_arg)
             }
         }
     };
-    auto write_lds = [&](int) {};
-#else
-    constexpr int K_LD = C::K_TILE_BYTES / 4096, V_LD = C::V_IMG_BYTES / 4096;
-    v4u kreg[K_LD], vreg[NH][V_LD];
-    auto issue_loads = [&](auto, int it, int) {
-#pragma unroll
-        for (int i = 0; i < K_LD; i++) {
-            const int piece = tid * K_LD + i;
-            const int row = piece / CPR, ch = piece % CPR;
-            int key = it * KT + row;
-            key = key < Lk ? key : Lk - 1;
-            kreg[i] = *reinterpret_cast<const v4u *>(kbase + (long)key * p.k_sl + ch * 16);
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            int tv = it * NH + hh;
-            tv = tv < ntk_all ? tv : ntk_all - 1;
-            const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
-#pragma unroll
-            for (int i = 0; i < V_LD; i++) vreg[hh][i] = *reinterpret_cast<const v4u *>(vt + (i * 256 + tid) * 16);
-        }
-    };
-    auto write_lds = [&](int buf) {
-        unsigned char *ks = smem + buf * C::STAGE_BYTES;
-        unsigned char *vs = ks + C::K_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < K_LD; i++) {
-            const int piece = tid * K_LD + i;
-            const int row = piece / CPR, ch = piece % CPR;
-            *reinterpret_cast<v4u *>(ks + row * D + swz_chunk<D>(row, ch) * 16) = kreg[i];
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++)
-#pragma unroll
-            for (int i = 0; i < V_LD; i++)
-                *reinterpret_cast<v4u *>(vs + hh * C::V_IMG_BYTES + (i * 256 + tid) * 16) = vreg[hh][i];
-    };
-#endif
 
     // ---- running state -------------------------------------------------------------------------
     v16f o[C::DT];
@@ -541,26 +435,17 @@ sage_attn_kernel(const AttnParams p_arg)
     // younger group) and then meets the others at a raw s_barrier -- __syncthreads() would drain
     // vmcnt(0) and expose the full L2/HBM latency every iteration (cdna_hip_programming.md T3+T4).
     constexpr int NSTAGE = C::NSTAGE;
-#if SAGE_GLDS
     constexpr int DMA_PER_TILE = KP / 4 + NH * (VP / 4);          // per wave
-#else
-    constexpr int DMA_PER_TILE = 0;
-#endif
     auto ring_wait = [&](bool younger_in_flight) {
-        if constexpr (NSTAGE == 3) {
-            if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            __syncthreads();
-        }
+        if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
     if (n_iters > 0) {
         load_kscales(0, ksc);
-        issue_loads(std::false_type{}, 0, 0);
-        write_lds(0);
+        issue_loads(0, 0);
     }
-    if (NSTAGE == 3 && n_iters > 1) issue_loads(std::false_type{}, 1, 1);
+    if (n_iters > 1) issue_loads(1, 1);
     // The Q fragments are fetched AFTER the first tiles' LDS-DMA has been issued: hipcc waits vmcnt(0) at the first use of an
     // ordinary VGPR load, and with the Q loads in front it did so after the first DMA instruction -- the Q round trip and the
     // tiles' round trip ran one after the other in every workgroup's prologue.
@@ -639,32 +524,26 @@ sage_attn_kernel(const AttnParams p_arg)
     }
 
     SAGE_TSTAMP(2);
-    ring_wait(NSTAGE == 3 && n_iters > 1);
+    ring_wait(n_iters > 1);
     SAGE_TSTAMP(3);
 
     int cur = 0;
-    // One K/V tile.  STEADY = the tile is whole and unmasked for every wave of the workgroup and tiles it+1, it+2
-    // exist and are whole: all wave-uniform conditionals of the general form fold away (the general iteration
-    // spends 14 scalar branches per tile on them).
-    auto tile_iter = [&](auto steady_tag, const int it) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const bool more = STEADY || (it + 1) < n_iters;
-        const bool more2 = STEADY || (it + 2) < n_iters;
+    // One K/V tile in the general form: masked, ragged, or one of a workgroup's last two (the whole, unmasked tiles in front of them run the
+    // software-pipelined loops below).
+    auto tile_iter = [&](const int it) {
+        const bool more = (it + 1) < n_iters;
+        const bool more2 = (it + 2) < n_iters;
         const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         float ksc_next[NH][2];
         if (more) load_kscales(it + 1, ksc_next);
-        if constexpr (NSTAGE == 3) {
-            if (more2) issue_loads(steady_tag, it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
-        } else {
-            if (more) issue_loads(std::false_type{}, it + 1, nxt);
-        }
+        if (more2) issue_loads(it + 2, (nxt + 1 == NSTAGE) ? 0 : nxt + 1);
 
         // number of 64-key halves with at least one key this wave may attend to (wave-uniform)
-        int nact = STEADY ? NH : 0;
+        int nact = 0;
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             const int key0 = it * KT + hh * BLKK;
-            if (!STEADY && key0 < Lk && (!CAUSAL || key0 <= crow0 + 31)) nact = hh + 1;
+            if (key0 < Lk && (!CAUSAL || key0 <= crow0 + 31)) nact = hh + 1;
         }
         // ---- attn_mask (Triton-named API only; attn_qk_int8_per_block.py:31-51): additive term per
         //      score in the log2 domain.  bool: 0 / -1e6, and a tile whose whole 128x64 mask block is
@@ -692,41 +571,19 @@ sage_attn_kernel(const AttnParams p_arg)
                 }
             if (MASK == 1) skip_tile = !__syncthreads_or(anytrue);
         }
-        if (STEADY || (nact > 0 && !skip_tile)) {
+        if (nact > 0 && !skip_tile) {
             const unsigned char *ks = smem + cur * C::STAGE_BYTES;
             const unsigned char *vs = ks + C::K_TILE_BYTES;
             const int last_key = it * KT + nact * BLKK - 1;
-            const bool full = STEADY || ((MASK == 0) && (nact == NH) && !(CAUSAL && last_key > crow0) && (last_key < Lk));
+            const bool full = (MASK == 0) && (nact == NH) && !(CAUSAL && last_key > crow0) && (last_key < Lk);
 
             // ---- S^T = K Q^T (int8 -> int32), NS sub-tiles of 32 keys ----
             v16i s[NS];
-#if SAGE_KPRELOAD
-            if constexpr (STEADY) {
-                // All K fragments of the tile are requested before the first MFMA and the two 32-key chains are
-                // interleaved.  Left alone, hipcc keeps ONE fragment buffer to save registers and emits
-                // ds_read -> wait -> MFMA six times per tile, exposing the LDS latency every time.
-                v4i kf[NS][C::KSTEPS];
-#pragma unroll
-                for (int sb = 0; sb < NS; sb++) {
-                    const int krow = sb * 32 + n;
-#pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++)
-                        kf[sb][kk] = *reinterpret_cast<const v4i *>(ks + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < C::KSTEPS; kk++)
-#pragma unroll
-                    for (int sb = 0; sb < NS; sb++) {
-                        s[sb] = kk == 0 ? mfma_i8_first(kf[sb][kk], qf[kk]) : __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[sb][kk], qf[kk], s[sb], 0, 0, 0);
-                    }
-            } else
-#endif
 #pragma unroll
             for (int sb = 0; sb < NS; sb++) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) s[sb][i] = 0;        // sub-tiles past the wave's last key are masked below
-                if (STEADY || sb < 2 * nact) {
+                if (sb < 2 * nact) {
                     const int krow = sb * 32 + n;
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
@@ -804,7 +661,7 @@ sage_attn_kernel(const AttnParams p_arg)
             constexpr bool sum_rounded = !PV_FP8 && !TWO_LEVEL;
             // FP8 PV, folded score form (SFOLD): as in the pipelined loop, the scale FMA reads the accumulator's bit pattern and subtracts
             // m + bias * c, rounded once per (row, tile, k scale) -- every tile of a launch uses ONE form, which the oracle mirrors
-            constexpr bool GFOLD = PV_FP8 && SFOLD && (SAGE_MAGIC != 0) && MASK == 0;
+            constexpr bool GFOLD = PV_FP8 && SFOLD && MASK == 0;
             float rs = 0.0f;
             auto p_chunk = [&](auto masked, auto rnd, int hh, int c, float (&e)[8]) {
                 const int sb = 2 * hh + (c >> 1), r0 = (c & 1) * 8;
@@ -867,23 +724,14 @@ sage_attn_kernel(const AttnParams p_arg)
                         } else acc = o[dt];
 #pragma unroll
                         for (int hh = 0; hh < NH; hh++) {
-                            if (STEADY || hh < nact) {
+                            if (hh < nact) {
                                 const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
                                 const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
                                 const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-#if SAGE_MXPV
                                 // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0)
                                 const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
                                 const v8i bv = {pw[hh][0], pw[hh][1], pw[hh][2], pw[hh][3], pw[hh][4], pw[hh][5], pw[hh][6], pw[hh][7]};
                                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-#else
-#define SAGE_L(lo, hi) ((long)(((unsigned long)(unsigned)(hi) << 32) | (unsigned long)(unsigned)(lo)))
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[0], va[1]), SAGE_L(pw[hh][0], pw[hh][1]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(va[2], va[3]), SAGE_L(pw[hh][2], pw[hh][3]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[0], vb[1]), SAGE_L(pw[hh][4], pw[hh][5]), acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(SAGE_L(vb[2], vb[3]), SAGE_L(pw[hh][6], pw[hh][7]), acc, 0, 0, 0);
-#undef SAGE_L
-#endif
                             }
                         }
                         if (FOLD) {
@@ -922,7 +770,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         } else acc = o[dt];
 #pragma unroll
                         for (int hh = 0; hh < NH; hh++) {
-                            if (STEADY || hh < nact) {
+                            if (hh < nact) {
                                 const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
 #pragma unroll
                                 for (int c = 0; c < 4; c++) {
@@ -943,7 +791,6 @@ sage_attn_kernel(const AttnParams p_arg)
         }
 
         if (more) {
-            write_lds(nxt);
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) { ksc[hh][0] = ksc_next[hh][0]; ksc[hh][1] = ksc_next[hh][1]; }
         }
@@ -952,8 +799,8 @@ sage_attn_kernel(const AttnParams p_arg)
     };
 
     int it = 0;
-#if SAGE_STEADY
-    if constexpr (MASK == 0 && NH == 1 && NSTAGE == 3) {
+    if constexpr (MASK == 0) {
+        static_assert(NH == 1 && NSTAGE == 3, "the pipelined loops are written for 64-key iterations on the 3-slot ring");
         // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
@@ -963,8 +810,7 @@ sage_attn_kernel(const AttnParams p_arg)
             n_steady = n_steady < nd ? n_steady : nd;
         }
 
-#if SAGE_PIPE
-        if constexpr (PV_FP8 && SAGE_MXPV && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
+        if constexpr (PV_FP8) {
             // ---- software-pipelined steady state -------------------------------------------------------------
             // Iteration t runs softmax(t) on the VALU and deals, between its instruction groups, the PV MFMAs of tile t-1
             // (P and V fragments carried in registers) and the QK^T MFMAs of tile t+1 (K fragments read at the top), so a
@@ -981,19 +827,10 @@ sage_attn_kernel(const AttnParams p_arg)
             // order O = O*alpha + P V, which the FP32 MFMA accumulator makes equivalent to the two-level fold.
             // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
             // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
-#define A_FMAN(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#define A_EXP(d, a)        asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a))
-#define A_ACC(d, a)        asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(a))
-#define A_PKLO(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
-#define A_PKHI(d, a, b)    asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(a), "v"(b))
-#define SAGE_NOPX "s_nop 1\n\t"
-#if SAGE_PLAIN_PV    // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix (same products; 8 bytes and one VGPR less per MFMA)
-#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#else
-#define A_PV(acc, av, bv, e8) asm volatile(SAGE_NOPX "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(av), "v"(bv), "v"(e8))
-#endif
+            // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix of its block-scaled form (same products; 8 bytes and one VGPR less per MFMA)
+#define A_PV(acc, av, bv)  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile(SAGE_NOPX "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
             if (it < n_steady) {
                 v16i sA[2], sB[2];
@@ -1017,7 +854,6 @@ sage_attn_kernel(const AttnParams p_arg)
                 v8i vf[C::DT];                                                        // V fragments of the previous tile
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) vf[dt] = v8i{0, 0, 0, 0, 0, 0, 0, 0};
-                [[maybe_unused]] const int e8m0 = 0x7f7f7f7f;     // unit block scales (SAGE_PLAIN_PV == 0)
                 static_assert(KP / 4 == VP / 4 && (KP / 4 == 1 || KP / 4 == 2), "asm LDS-DMA: one or two pieces per wave and image");
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
                 const unsigned voff16 = lane * 16;
@@ -1074,7 +910,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
                     // (nothing is in flight on lgkmcnt here, so hipcc's own wait for the V fragments in front of this MFMA is free;
                     //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
-                    A_PV(o[0], vf[0], pp, e8m0);
+                    A_PV(o[0], vf[0], pp);
                     A_FENCE();
                     float ksc_next[NH][2];
                     load_kscales(it + 1, ksc_next);
@@ -1100,7 +936,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     // SFOLD: what the scale FMA subtracts is the row maximum plus the bias of the score's bit pattern in this tile's scale
                     const float mb0 = SFOLD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new) : m_new;
                     const float mb1 = (SFOLD && KTHREAD) ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
-                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp, e8m0);
+                    if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp);
                     A_FENCE();
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
@@ -1141,8 +977,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         const v4u b = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
                         vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
                     };
-#if SAGE_GRP4
-                    // experiment: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
+                    // D = 128: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
                     // can sit between the exponentials and the adds
                     float u0, u1, u2, u3;
                     auto g4a = [&](int w) {
@@ -1167,9 +1002,9 @@ sage_attn_kernel(const AttnParams p_arg)
                                      : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
                     };
                     if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp, e8m0);
+                        A_PV(o[2], vf[2], pp);
                         g4a(0); g4b(0);
-                        A_PV(o[3], vf[3], pp, e8m0);
+                        A_PV(o[3], vf[3], pp);
                         g4a(1); g4b(1);
                         qk_next(0, 0); g4a(2);
                         qk_next(0, 1); g4b(2); g4a(3);
@@ -1183,25 +1018,6 @@ sage_attn_kernel(const AttnParams p_arg)
                         qk_next(1, 3);
                         A_FENCE(); read_v(2); read_v(3); A_FENCE();
                         g4a(7); g4b(7);
-                    } else
-#endif
-                    if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp, e8m0);
-                        grp(0); grp(1);
-                        A_PV(o[3], vf[3], pp, e8m0);
-                        grp(2); grp(3);
-                        qk_next(0, 0); grp(4);
-                        qk_next(0, 1); grp(5); grp(6);
-                        qk_next(0, 2); grp(7);
-                        qk_next(0, 3); grp(8);
-                        A_FENCE(); read_v(0); read_v(1); A_FENCE();
-                        grp(9);
-                        qk_next(1, 0); grp(10);
-                        qk_next(1, 1); grp(11); grp(12);
-                        qk_next(1, 2); grp(13);
-                        qk_next(1, 3);
-                        A_FENCE(); read_v(2); read_v(3); A_FENCE();
-                        grp(14); grp(15);
                     } else {                         // D = 64: two PV MFMAs (dealt above), four QK^T MFMAs
                         grp(0); grp(1); grp(2); grp(3);
                         qk_next(0, 0); grp(4); grp(5); grp(6);
@@ -1235,24 +1051,16 @@ sage_attn_kernel(const AttnParams p_arg)
                 // iteration issues the LDS-DMA of tile it+2 into that slot
                 rescale();
 #pragma unroll
-                for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA, e8m0);
+                for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA);
                 load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                 __builtin_amdgcn_s_barrier();
             }
-#undef A_FMAN
-#undef A_EXP
-#undef A_ACC
-#undef A_PKLO
-#undef A_PKHI
 #undef A_PV
 #undef A_QK0
 #undef A_QK
 #undef A_FENCE
-        } else
-#endif
-#if SAGE_PIPE && SAGE_PIPE16
-        if constexpr (!PV_FP8 && SAGE_MAGIC && (!TWO_LEVEL || SAGE_DIRECT)) {
+        } else {
             // ---- software-pipelined steady state, FP16 PV --------------------------------------------------------------------
             // Same structure as the FP8 loop above; differences:
             //  * PV(t-1) is 4 x DT v_mfma_f32_32x32x16_f16 whose V fragments do not fit in registers next to two score tiles,
@@ -1261,13 +1069,8 @@ sage_attn_kernel(const AttnParams p_arg)
             //    V regions are filled separately: at the top of iteration t the LDS-DMA brings K(t+2) into the K region of
             //    slot (t+2)%3 (K(t-1), read in iteration t-2, is dead) and V(t+1) into the V region of slot (t+1)%3 (V(t-2),
             //    read in iteration t-1, is dead); K(t+1) and V(t-1) were requested one and two iterations ago.
-#if SAGE_FOLDBIAS
 #define SAGE_SCALE2 SAGE_SCALE2_FOLD
-#else
-#define SAGE_SCALE2 SAGE_SCALE2_EXACT
-#endif
 #define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#define A_RS0(acc, av, bv)  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
 #define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
@@ -1311,16 +1114,6 @@ sage_attn_kernel(const AttnParams p_arg)
                 // CUDA kernel form (TWO_LEVEL false): row sum of the fp16-rounded P; Triton kernel form (TWO_LEVEL true): of the
                 // un-rounded P (see tile_iter)
                 constexpr bool RSUM16 = !TWO_LEVEL;
-                constexpr bool RSMFMA = RSUM16 && SAGE_RSUM_MFMA && D == 128;       // (D = 64: spills at three waves)
-                // RSMFMA: rsacc = ones(32 x 16) . P(t-1)^T chunk by chunk beside the PV MFMAs: every register of the lane holds the
-                // whole row sum of its query row (both lane halves); it joins l one tile late, l(t-1) = l + rs(t-1), then * alpha(t)
-                [[maybe_unused]] v16f rsacc;
-                [[maybe_unused]] v4i ones16 = {0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};
-                if constexpr (RSMFMA) {
-                    asm volatile("" : "+v"(ones16));
-#pragma unroll
-                    for (int i = 0; i < 16; i++) rsacc[i] = 0.0f;
-                }
                 auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
                     rescale();
                     const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
@@ -1380,12 +1173,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     const float m_new = fmaxf(m_run, pair_max(mxc));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
-#if SAGE_FOLDBIAS
                     const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
                     const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
-#else
-                    const float mb0 = m_new, mb1 = m_new;
-#endif
                     A_FENCE();
                     if constexpr (C::DT > 1) read_v(1, vfb);
                     A_FENCE();
@@ -1397,13 +1186,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
                         const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
-                        if constexpr (RSMFMA) {
-                            asm volatile(SAGE_SCALE2("%0", "%1", "%3", "%4", "%5", "%6", "%7")
-                                         "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\t"
-                                         "s_nop 0\n\tv_cvt_pk_f16_f32 %2, %0, %1"
-                                         : "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
-                        } else if constexpr (RSUM16) {
+                        if constexpr (RSUM16) {
                             // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
                             // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
                             // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
@@ -1434,9 +1217,6 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     auto pv4 = [&](int dt, v4i (&vf)[4], int c) {
                         A_PV16(o[dt], vf[c], pp[c]);
-                        if constexpr (RSMFMA) {                                  // the row-sum MFMA of chunk c rides behind channel tile 1 (D=64: 0)
-                            if (dt == (C::DT == 4 ? 1 : 0)) { if (c == 0) A_RS0(rsacc, ones16, pp[0]); else A_PV16(rsacc, ones16, pp[c]); }
-                        }
                     };
                     auto qk_next = [&](int sb, int kk) {
                         if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
@@ -1490,8 +1270,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     A_FENCE();
                     float ksc_next[NH][2];
                     load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
-                    if constexpr (RSMFMA) l_run = (l_run + (g == 0 ? rsacc[0] : 0.0f)) * alpha;     // lane-partial convention: half 0 carries the sum
-                    else l_run = l_run * alpha + (rs0 + rs1);
+                    l_run = l_run * alpha + (rs0 + rs1);
                     ksc[0][0] = ksc_next[0][0];
                     ksc[0][1] = ksc_next[0][1];
                     cur = nxt;
@@ -1544,34 +1323,18 @@ sage_attn_kernel(const AttnParams p_arg)
                             A_PV16(o[dt], a, pA[c]);
                         }
                     }
-                    if constexpr (RSMFMA) {
-                        A_RS0(rsacc, ones16, pA[0]);
-#pragma unroll
-                        for (int c = 1; c < 4; c++) A_PV16(rsacc, ones16, pA[c]);
-                    }
                     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VP / 4) : "memory");
-                    if constexpr (RSMFMA) {
-                        asm volatile("" : "+v"(rsacc));          // (ordered behind the nops, like sA: the sum below reads an MFMA result)
-                        l_run += (g == 0 ? rsacc[0] : 0.0f);
-                    }
                     __builtin_amdgcn_s_barrier();
                 }
             }
-#undef A_RS0
 #undef SAGE_SCALE2
 #undef A_PV16
 #undef A_QK0
 #undef A_QK
 #undef A_FENCE
-        } else
-#endif
-        {
-#pragma nounroll
-            for (; it < n_steady; it++) tile_iter(std::true_type{}, it);
         }
     }
-#endif
     if constexpr (PERS_OK) {
         // the general iterations' per-lane LDS offsets are re-derived here: formed before the pipelined loop they stay live across it, and the
         // D = 64 per-thread instantiation with the folded score form then spills one of them (8 bytes of scratch for one store per item)
@@ -1581,7 +1344,7 @@ sage_attn_kernel(const AttnParams p_arg)
         g = lane_t >> 5;
     }
 #pragma nounroll
-    for (; it < n_iters; it++) tile_iter(std::false_type{}, it);
+    for (; it < n_iters; it++) tile_iter(it);
     SAGE_TSTAMP(4);
     __syncthreads();      // (raw barriers above do not order the epilogue's LDS reuse against stray waits)
     SAGE_TSTAMP(5);
@@ -1746,17 +1509,17 @@ static hipError_t launch_kernel(int lds, const AttnParams &p, int nwork, const A
 
 // The members of the family one instantiation unit holds: INT8 q (8 of causal x k-scale groups x accumulation), the fused per-thread Q
 // quantiser (fp16 / bf16 q), and for FP16 PV the masked kernels and the fused per-block Q quantiser.
-// Keys per iteration: 128 (NH = 2) where two workgroups still fit a CU's LDS, else 64 -- SAGE_NH_F8, 1 today.
+// Keys per iteration: 64 (NH = 1).
 template <int D, bool PV_FP8, bool SFOLD>
 hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork, const AttnLaunchOpts &l)
 {
     static_assert(PV_FP8 || SFOLD, "FP16 PV has one score form");
-    constexpr int NH = (PV_FP8 || D == 64) ? SAGE_NH_F8 : 1;
+    constexpr int NH = 1;
     using C = TileCfg<D, PV_FP8, NH>;
     // causal launches take the ticket route only over a packed batch's work list (items of very different lengths, heaviest first: +2.9 % at
     // C4), in instantiations of their own (CPERS); dense causal launches keep the hardware's dispatch, which their work order is built on
     const bool packed_list = p.cu_q != nullptr && p.work_items != nullptr;
-    const bool pers = !v.causal || SAGE_PERS_CAUSAL != 0;
+    const bool pers = !v.causal;
     if (v.mask_kind != 0) {       // Triton-named API: FP16 PV, per-block scales, non-causal, tile product folded into the FP32 output
         if constexpr (!PV_FP8) {
             using CM = TileCfg<D, false, 1>;
@@ -1775,7 +1538,7 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
     }
     if (v.qf == 3 || v.qf == 4) {      // per-block Q in the prologue: the Triton-named API's kernels (FP16 PV, per-block k scales), dense or varlen
         if constexpr (!PV_FP8) {
-            if (v.causal && packed_list && SAGE_PERS_QF != 0) {
+            if (v.causal && packed_list) {
                 if (v.qf == 3) return launch_kernel<sage_attn_kernel<D, false, true, false, true, NH, 0, 3, true, true>>(C::LDS_BYTES, p, nwork, l, true);
                 return launch_kernel<sage_attn_kernel<D, false, true, false, true, NH, 0, 4, true, true>>(C::LDS_BYTES, p, nwork, l, true);
             }
