@@ -205,11 +205,23 @@ def prequantize(cfg, q, k, v):
     return q8, qs, k8, ks, vimg, vscale, _cabi.GRAN_PER_THREAD, 32, sm * 1.44269504
 
 
-def kernel_only_step(cfg, ops, sm_scale=None):
+def kernel_only_step(cfg, ops, sm_scale=None, folded=None):
+    """One launch of the attention kernel on pre-quantised operands.  folded: None = the process default FP8 score form (exact -- the reference's
+    formula -- unless SAGE_FP8_SCORES says otherwise), True = the opt-in folded variant."""
     from sageattention_amd import core, ops as sa_ops
     q8, qs, k8, ks, vimg, vscale, gran, q_warp, sm_log2 = ops
     return core._attn_dense(cfg["pv"] == "fp8", q8, k8, vimg, vscale, qs, ks, _dtype(cfg), "HND", cfg["causal"],
-                            gran, q_warp, sm_log2, cfg["pv"] == "fp8", False, exact_scores=sa_ops.fp8_exact(None))[0]      # (the process default: SAGE_FP8_SCORES)
+                            gran, q_warp, sm_log2, cfg["pv"] == "fp8", False, folded_scores=sa_ops.fp8_folded(None) if folded is None else folded)[0]
+
+
+def folded_variant(cfg, ops, fl, steps, warmup, ramp):
+    """The opt-in folded FP8 score form (fp8_scores="folded", SAGE_ATTR_FP8_FOLDED_SCORES) timed beside the default: NOT the reference's
+    arithmetic, reported so that what the default's exactness costs is on the record."""
+    _, d = timed(lambda: kernel_only_step(cfg, ops, folded=True), steps, warmup, False, ramp)
+    ms = sum(d) / len(d)
+    r = roofline_obj(fl, ms, "fp8", "sage_attn_kernel, SFOLD = true (opt-in variant)", None)
+    return {"what": "the same launch with fp8_scores=\"folded\": one FMA per score, m + bias c' rounded once per (row, tile, k scale); opt-in, not the default, "
+                    "not the reference's formula", "ms_per_launch": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "roofline": r}
 
 
 def e2e_step(cfg, q, k, v):
@@ -400,6 +412,11 @@ def measure_c4(steps, warmup, ramp, device):
     return out
 
 
+def _score_form():
+    from sageattention_amd import ops as sa_ops
+    return "folded" if sa_ops.fp8_folded(None) else "exact"
+
+
 def measure_dense(name, cfg, device, steps, warmup, ramp, with_e2e=True):
     """kernel-only + roofline (+ whole call) of one dense configuration on this device."""
     q, k, v = make_inputs(cfg, device, 1234)
@@ -410,6 +427,9 @@ def measure_dense(name, cfg, device, steps, warmup, ramp, with_e2e=True):
     out = {"workload": cfg["workload"], "dtype": "int8 QK^T + " + ("fp8(e4m3) PV" if cfg["pv"] == "fp8" else "fp16 PV") + ", fp32 accumulate",
            "kernel_only": {"ms_per_launch": round(kern_ms, 4), "tflops": round(fl / kern_ms / 1e9, 2)},
            "roofline": roofline_obj(fl, kern_ms, cfg["pv"], "sage_attn_kernel", name)}
+    if cfg["pv"] == "fp8":
+        out["fp8_score_form"] = _score_form()
+        out["fp8_folded_variant"] = folded_variant(cfg, ops, fl, max(5, steps // 2), 3, ramp)
     if with_e2e:
         n = max(3, steps // 2)
         wall, _ = timed(lambda: e2e_step(cfg, q, k, v), n, 2, False, ramp)
@@ -704,7 +724,8 @@ def main():
         "vs_baseline": round(value / world / 795.0, 4) if args.config == "c3" else None,
         "vs_baseline_note": "per-GPU kernel-only TFLOPS / 795 (SageAttn2-8b, H100, hd128 causal N=8k; BASELINE.md section 1)",
         "dtype": "int8 QK^T + " + ("fp8(e4m3) PV" if cfg["pv"] == "fp8" else "fp16 PV") + ", fp32 accumulate",
-        "fp8_score_form": (("exact" if __import__("sageattention_amd.ops", fromlist=["_FP8_EXACT"])._FP8_EXACT else "folded") if cfg["pv"] == "fp8" else None),
+        "fp8_score_form": _score_form() if cfg["pv"] == "fp8" else None,
+        "fp8_score_form_note": "exact = exp2(fma(s, c, -m)) as the reference's kernels evaluate it (attn_utils.cuh:445-449): the default of every entry point",
         "data": "synthetic (randn, quantised by the product's own pre-pass kernels)",
         "config": {"workload": cfg["workload"], "global_batch": cfg["B_global"] * world, "heads": CONFIGS[args.config]["H"], "seq_len": cfg["N"],
                    "head_dim": cfg["D"], "parallelism": f"batch*head shard x{world} (shard.shard_range units of the global batch), no collective"},
@@ -714,6 +735,8 @@ def main():
                        "what": "sageattn(): K mean + INT8 Q/K quant + V pre-pass + attention",
                        "prepass": prepass},
     }
+    if cfg["pv"] == "fp8" and world == 1:
+        out["fp8_folded_variant"] = folded_variant(cfg, ops, fl, max(10, args.steps // 2), 5, min(args.ramp_seconds, 0.2))
     if ranks_seen is not None:
         out["ranks_seen"] = ranks_seen
         out["ms_per_step_per_rank"] = per_rank_ms

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 19
+#define SAGE_ABI_VERSION 20
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -299,18 +299,19 @@ typedef struct SageLaunchAttr {
     int32_t trace_wgs;
     int32_t reserved;
 } SageLaunchAttr;
-/* FP8 PV only.  The softmax argument of a score is fma(s, c, -m) with s the INT32 dot product, c the dequantisation scale in the log2
- * domain and m the running row maximum (attn_utils.cuh:445-449).  The kernels read the accumulator's bit pattern as the float
- * bias + s * 2^-26 (bias = 0x3E22F983 as a float, exact).  Default ("folded"): one FMA per score, fma(bits, c', -(m + bias * c')) with
- * m + bias * c' rounded once per (row, 64-key tile, k scale) -- up to 0.64 of one INT8 x INT8 score step of error in the exponent, which
- * re-rolls a few e4m3 roundings of P per row (statistically the same result; measured against the exact form: DESIGN.md 4).  With this
- * flag ("exact"): the bias is subtracted first (exact, Sterbenz), then the FMA -- bit for bit the reference's formula, 3-7 % slower.
- * The oracle has both forms (oracle/sage_oracle.c score_mode); each form is held to 2e-3 * max|o| against its own.
- * Range: the folded form rounds m + bias c' at the magnitude of bias c', an error of up to 0.32 c in the exponent of a (row, tile, k scale) group,
- * c = sm_scale log2(e) q_scale k_scale = the exponent change per INT8 x INT8 score step (1e-4 ... 1e-2 on ordinary inputs).  It is meant for c << 0.1;
- * inputs with |q|, |k| in the hundreds (c >= 0.1) should take the exact form.  Either way P saturates like the reference's cvt.rn.satfinite (no NaN;
- * profiles/r5_run_i_score_scale_range.txt). */
+/* The softmax argument of a score is fma(s, c, -m) with s the INT32 dot product, c the dequantisation scale in the log2 domain and m the
+ * running row maximum (attn_utils.cuh:445-449).  The kernels read the accumulator's bit pattern as the float bias + s * 2^-26
+ * (bias = 0x3E22F983 as a float, exact), subtract the bias (exact, Sterbenz) and take that FMA: bit for bit the reference's formula, on every
+ * input.  That is the DEFAULT of every entry point since ABI 20 (attr == NULL included), for FP8 and FP16 PV.
+ * SAGE_ATTR_FP8_FOLDED_SCORES (FP8 PV only, opt-in; ABI 19's default): one FMA per score, fma(bits, c', -(m + bias * c')) with m + bias * c'
+ * rounded once per (row, 64-key tile, k scale) -- 3-7 % faster, NOT the reference's arithmetic: an error of up to 0.32 c in the exponent of a
+ * (row, tile, k scale) group, c = sm_scale log2(e) q_scale k_scale = the exponent change per INT8 x INT8 score step (1e-4 on randn inputs, 1e-2 with
+ * activations of a few tens), which re-rolls e4m3 roundings of P (single outputs move by up to 1.4e-2 * max|o|, rel-RMS 1e-3 ... 2e-3; statistically
+ * the same result against fp32 attention) and from c ~ 0.1 on loses whole rows (profiles/r5_run_i_score_scale_range.txt).  A variant for callers who
+ * know their magnitudes; the oracle mirrors it (oracle/sage_oracle.c score_mode 1) so that it can be tested, nothing more.
+ * SAGE_ATTR_FP8_EXACT_SCORES: what ABI 19 callers set to obtain today's default; still accepted, no effect. */
 #define SAGE_ATTR_FP8_EXACT_SCORES 1u
+#define SAGE_ATTR_FP8_FOLDED_SCORES 4u
 /* tests: take the persistent route from two rounds of workgroups up instead of twelve (needs launch_ws) */
 #define SAGE_ATTR_FORCE_PERSISTENT 2u
 SAGE_API int64_t sage_attn_launch_ws_bytes(void);

@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 19
+ABI_VERSION = 20
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
 QSTYLE_TRITON, QSTYLE_CUDA, QSTYLE_TRITON_THREAD = 0, 1, 2
 PV_ACCUM_SINGLE, PV_ACCUM_TWO_LEVEL, PV_ACCUM_TRITON = 0, 1, 2   # 2: FP16 PV, the reference's Triton kernel form
 MASK_BOOL, MASK_F16, MASK_BF16 = 1, 2, 3
-ATTR_FP8_EXACT_SCORES, ATTR_FORCE_PERSISTENT = 1, 2
+ATTR_FP8_EXACT_SCORES, ATTR_FORCE_PERSISTENT, ATTR_FP8_FOLDED_SCORES = 1, 2, 4
 
 
 class SageLaunchAttr(ctypes.Structure):
@@ -31,15 +31,15 @@ class SageLaunchAttr(ctypes.Structure):
                 ("grid_out", c_void_p), ("trace", c_void_p), ("trace_wgs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-def launch_attr(launch_ws=None, exact_scores: bool = False, force_persistent: bool = False, grid_out=None, trace=None, trace_wgs: int = 0):
+def launch_attr(launch_ws=None, folded_scores: bool = False, force_persistent: bool = False, grid_out=None, trace=None, trace_wgs: int = 0):
     """A ``SageLaunchAttr`` (or None when every field is at its default).  ``launch_ws``: a zeroed int32 CUDA tensor of
     ``sage_attn_launch_ws_bytes()`` bytes; the caller keeps it (and the returned struct) alive until the C call has returned.
     ``grid_out``: a ``ctypes.c_int32`` that receives the number of workgroups launched."""
-    if launch_ws is None and not exact_scores and grid_out is None and trace is None:
+    if launch_ws is None and not folded_scores and grid_out is None and trace is None:
         return None
     a = SageLaunchAttr()
     a.struct_bytes = ctypes.sizeof(SageLaunchAttr)
-    a.flags = (ATTR_FP8_EXACT_SCORES if exact_scores else 0) | (ATTR_FORCE_PERSISTENT if force_persistent else 0)
+    a.flags = (ATTR_FP8_FOLDED_SCORES if folded_scores else 0) | (ATTR_FORCE_PERSISTENT if force_persistent else 0)
     if launch_ws is not None:
         a.launch_ws = launch_ws.data_ptr()
         a.launch_ws_bytes = launch_ws.numel() * launch_ws.element_size()

@@ -75,7 +75,7 @@ def _smooth_k(q, k, tensor_layout, smooth_k, return_lse):
 
 
 def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dtype, tensor_layout, is_causal,
-                gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None, exact_scores=False):
+                gran, q_warp, sm_scale_log2, two_level, return_lse, v_mean=None, folded_scores=False):
     """Allocate ``o`` and launch the fused kernel through the registered custom op (-> C ABI)."""
     B, Hq, Lq, D, _, _, _ = _dims(q_int8, tensor_layout)
     Hkv = _dims(k_int8, tensor_layout)[1]
@@ -91,7 +91,7 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     f16 = ops.qk_int8_sv_f16_attn if compiling else ops.qk_int8_sv_f16_attn_impl
     if fp8:
         lse = f8(q_int8, k_int8, v_image, o, q_scale, k_scale, v_scale, v_mean, layout, int(is_causal),
-                 gran, q_warp, float(sm_scale_log2), accum, int(return_lse), bool(exact_scores))
+                 gran, q_warp, float(sm_scale_log2), accum, int(return_lse), bool(folded_scores))
     else:
         lse = f16(q_int8, k_int8, v_image, o, q_scale, k_scale, v_mean, layout, int(is_causal),
                   gran, q_warp, float(sm_scale_log2), accum, int(return_lse))
@@ -99,7 +99,7 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
 
 
 @torch.compiler.disable
-def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None, exact_scores=False):
+def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None, folded_scores=False):
     """FP8-PV two-level attention with the per-thread Q quantisation done in the kernel prologue
     (``sage_attn_fused_q_pv_f8``): bit-identical to ``per_thread_int8`` + the attention op, one launch and
     3 B/element of HBM traffic less."""
@@ -111,7 +111,7 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
     # (a large non-causal call: persistent launch; FP8 PV: the score form)
-    attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128), exact_scores and v_scale is not None)
+    attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128), folded_scores and v_scale is not None)
     if v_scale is None:            # FP16 PV (v_image from prep_v_fp16), straight FP32 accumulation
         rc = _cabi.load().sage_attn_fused_q_pv_f16(
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
@@ -188,7 +188,7 @@ def _split_kv_plan(B: int, Hq: int, Lq: int, Lk: int, is_causal: bool, override,
 
 @torch.compiler.disable
 def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, S, return_lse, v_mean=None,
-                        exact_scores=False):
+                        folded_scores=False):
     """Split-KV route of the fused-Q FP8 attention: the key range in S chunks folded into the kv-head dimension (zero-copy
     views of the INT8 K, its scales and the V image; Q is read in place by every chunk), partial outputs in fp16 +
     log2-domain log-sum-exps, one ``sage_merge_split`` pass."""
@@ -218,7 +218,7 @@ def _attn_fused_q_split(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_
             _p(q), _p(k_f), _p(v_image), _p(o_part), _p(lse_part), _p(ks_f), _p(vs_f), _p(vm_f),
             B, Hq, Hkv, S, Lq, Lc, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, p_sb, p_sh, p_sl,
             int(is_causal), float(sm_scale_log2), code, _cabi.DTYPE_F16, _stream(q),
-            _cabi.attr_arg(_cabi.launch_attr(exact_scores=bool(exact_scores))))
+            _cabi.attr_arg(_cabi.launch_attr(folded_scores=bool(folded_scores))))
         _cabi.check(rc, "sage_attn_fused_q_pv_f8_split")
     o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(o, tensor_layout)
@@ -600,7 +600,7 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         smooth_v = False
     fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp32" and kwargs.get("fuse_q_quant", True)
     fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")) and k.shape == v.shape
-    exact = ops.fp8_exact(kwargs.get("fp8_scores"))
+    folded = ops.fp8_folded(kwargs.get("fp8_scores"))
     if fuse_q:
         # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM).
         # (Running the V pre-pass on a side stream beside the K chain was measured and rejected: the two HBM-bound chains
@@ -611,16 +611,16 @@ def sageattn_qk_int8_pv_fp8_cuda(q, k, v, tensor_layout: str = "HND", is_causal:
         n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"), auto_default=False)
         if n_split:
             o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal,
-                                         _sm_log2(sm_scale), n_split, return_lse, v_mean=vm, exact_scores=exact)
+                                         _sm_log2(sm_scale), n_split, return_lse, v_mean=vm, folded_scores=folded)
         else:
             o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
-                                   return_lse, v_mean=vm, exact_scores=exact)
+                                   return_lse, v_mean=vm, folded_scores=folded)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     lse_correction, _, k_int8, k_scale, v_image, v_scale, vm = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, smooth_v,
                                                                            return_lse, fused)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 32, sm_scale)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm, exact_scores=exact)
+                         gran, q_warp, sm_log2, pv_accum_dtype != "fp32", return_lse, v_mean=vm, folded_scores=folded)
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
 
 
@@ -650,5 +650,5 @@ def sageattn_qk_int8_pv_fp8_cuda_sm90(q, k, v, tensor_layout: str = "HND", is_ca
                                                                           return_lse, fused)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, 16, sm_scale, blkk=128)
     o, lse = _attn_dense(True, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, dtype, tensor_layout, is_causal,
-                         gran, q_warp, sm_log2, True, return_lse, exact_scores=ops.fp8_exact(kwargs.get("fp8_scores")))
+                         gran, q_warp, sm_log2, True, return_lse, folded_scores=ops.fp8_folded(kwargs.get("fp8_scores")))
     return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)

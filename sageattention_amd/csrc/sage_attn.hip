@@ -50,11 +50,11 @@ static hipError_t launch_unit(const AttnParams &p, int head_dim, bool pv_fp8, co
 {
     if (head_dim == 128) {
         if (!pv_fp8) return launch_attn_part<128, false, true>(p, v, nwork, o);
-        return o.fp8_exact ? launch_attn_part<128, true, false>(p, v, nwork, o) : launch_attn_part<128, true, true>(p, v, nwork, o);
+        return o.fp8_folded ? launch_attn_part<128, true, true>(p, v, nwork, o) : launch_attn_part<128, true, false>(p, v, nwork, o);
     }
     if (head_dim == 64) {
         if (!pv_fp8) return launch_attn_part<64, false, true>(p, v, nwork, o);
-        return o.fp8_exact ? launch_attn_part<64, true, false>(p, v, nwork, o) : launch_attn_part<64, true, true>(p, v, nwork, o);
+        return o.fp8_folded ? launch_attn_part<64, true, true>(p, v, nwork, o) : launch_attn_part<64, true, false>(p, v, nwork, o);
     }
     return hipErrorInvalidValue;
 }

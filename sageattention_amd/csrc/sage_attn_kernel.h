@@ -1,5 +1,5 @@
 // sage_attn_kernel.h -- fused INT8-QK^T / online-softmax / FP8-or-FP16-PV attention for gfx950: the kernel family and its launcher.
-// Included by the instantiation units sage_attn_d{128,64}_{f8,f8x,f16}.hip (one per head size, PV format and FP8 score form, so that they
+// Included by the instantiation units sage_attn_d{128,64}_{f8,f8f,f16}.hip (one per head size, PV format and FP8 score form, so that they
 // compile in parallel); sage_attn.hip holds the host-side dispatch.
 //
 // Replaces (behaviourally, not textually) the reference kernels
@@ -57,8 +57,8 @@
 #define SAGE_MIN_WAVES(D, MASK) ((MASK) != 0 ? 2 : ((D) == 64 ? 3 : 2))
 
 // asm text of the pipelined loops: two scores d0 / d1 from the bit patterns s0 / s1 of the QK^T accumulators, d = score * c - m (operands as
-// asm placeholders).  FOLD: one FMA per score, m already carries the bias of the bit pattern (SAGE_FOLDBIAS); EXACT: the bias is
-// subtracted first (exact), then the FMA
+// asm placeholders).  EXACT: the bias of the bit pattern is subtracted first (exact), then the FMA; FOLD (the FP8 opt-in variant): one FMA per
+// score, m already carries the bias
 #define SAGE_SCALE2_FOLD(d0, d1, s0, s1, c0, c1, m) "v_fma_f32 " d0 ", " s0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " s1 ", " c1 ", -" m "\n\t"
 #define SAGE_SCALE2_EXACT(d0, d1, s0, s1, c0, c1, m) "v_add_f32 " d0 ", 0xbe22f983, " s0 "\n\tv_add_f32 " d1 ", 0xbe22f983, " s1 "\n\t" \
                                                       "v_fma_f32 " d0 ", " d0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " d1 ", " c1 ", -" m "\n\t"
@@ -114,8 +114,10 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 // 3 / 4 = fp16 / bf16 quantised in the prologue PER BLOCK of 128 rows after the multiplication by p.q_premul (quant_per_block.py:21-46
 // with sm_scale folded in: the Q half of the reference's Triton-named API and of sageattn_varlen),
 // ("per-thread" groups, quant_per_thread.py:21-52), so the INT8 copy of Q and its scales never touch HBM.
-// SFOLD (FP8 PV only): true = the bias of the score's bit pattern is folded into the scale FMA in every tile of the launch, false = the exact
-// subtraction (see SAGE_FOLDBIAS above); FP16-PV instantiations pass true and fold in their pipelined loop only, as since round 4.
+// SFOLD (FP8 PV only): false = the exact score form, exp2(fma(s, c, -m)) with the bias of the score's bit pattern subtracted first -- the
+// reference's formula (attn_utils.cuh:445-449), the default of every entry point; true = the opt-in variant SAGE_ATTR_FP8_FOLDED_SCORES, the bias
+// folded into the scale FMA in every tile of the launch (exp2(fma(bits, c', -(m + bias c'))): one VALU instruction less per score, m + bias c'
+// rounded once per (row, tile, k scale); the oracle's score_mode 1 mirrors it).  FP16-PV instantiations have one form, the exact one, and pass true.
 // CPERS: the persistent ticket loop compiled into a CAUSAL instantiation (the packed route's launches over the work list; non-causal unmasked
 // instantiations always carry it).
 template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true, bool CPERS = false>
@@ -1069,7 +1071,17 @@ sage_attn_kernel(const AttnParams p_arg)
             //    V regions are filled separately: at the top of iteration t the LDS-DMA brings K(t+2) into the K region of
             //    slot (t+2)%3 (K(t-1), read in iteration t-2, is dead) and V(t+1) into the V region of slot (t+1)%3 (V(t-2),
             //    read in iteration t-1, is dead); K(t+1) and V(t-1) were requested one and two iterations ago.
-#define SAGE_SCALE2 SAGE_SCALE2_FOLD
+            //  * FP16 PV rounds P to 2^-11, so the running maximum the exponent is taken against need not be the true one: m_run is a
+            //    REFERENCE that is refreshed (and O, l rescaled) only when a row of the wave has a score more than kLazyTau above it -- P <= 2^kLazyTau
+            //    fits fp16 with its full mantissa, small probabilities keep more of theirs, and softmax is invariant to the reference.  The
+            //    reference's kernels update m and rescale every tile (attn_utils.cuh:394-431); on random data a wave then rescales its 64 O
+            //    registers in 60-85 % of the tiles of a C2 block (some row of 32 sets a record), here once or twice per work item.  FP8 PV
+            //    cannot do this: e4m3's 2^-4 rounding of P is re-rolled by any change of the reference.
+            //    The scores themselves take the exact form fma(s, c, -m) (SAGE_SCALE2_EXACT), as the reference's (attn_utils.cuh:445-449).
+#ifndef SAGE_FP16_LAZY       // A/B of round 6: 0 = refresh whenever a maximum of the wave moves (rounds 2-5)
+#define SAGE_FP16_LAZY 1
+#endif
+#define SAGE_SCALE2 SAGE_SCALE2_EXACT
 #define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
 #define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
@@ -1101,9 +1113,11 @@ sage_attn_kernel(const AttnParams p_arg)
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
                 const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
+                constexpr float kLazyTau = SAGE_FP16_LAZY ? 8.0f : 0.0f;
                 float alpha_p = 1.0f;
+                bool moved_p = false;              // wave-uniform: the previous tile refreshed the reference, O owes alpha_p
                 auto rescale = [&]() {
-                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
+                    if (moved_p) {
 #pragma unroll
                         for (int dt = 0; dt < C::DT; dt++)
 #pragma unroll
@@ -1170,11 +1184,12 @@ sage_attn_kernel(const AttnParams p_arg)
                         }
                     float mxc = __builtin_fmaf(sfl(mx0), cs[0], -OFF);
                     if (KTHREAD) mxc = fmaxf(mxc, __builtin_fmaf(sfl(mx1), cs[1], -OFF));
-                    const float m_new = fmaxf(m_run, pair_max(mxc));
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    const float m_t = pair_max(mxc);
+                    const bool moved = __builtin_amdgcn_ballot_w64(m_t > m_run + kLazyTau) != 0;       // some row of the wave left the window
+                    const float m_new = moved ? fmaxf(m_run, m_t) : m_run;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // (1.0 where the reference stays)
                     m_run = m_new;
-                    const float mb0 = __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new);
-                    const float mb1 = KTHREAD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
+                    const float mb0 = m_new, mb1 = m_new;
                     A_FENCE();
                     if constexpr (C::DT > 1) read_v(1, vfb);
                     A_FENCE();
@@ -1275,6 +1290,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     ksc[0][1] = ksc_next[0][1];
                     cur = nxt;
                     alpha_p = alpha;
+                    moved_p = moved;
                     it++;
                 };
                 if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)

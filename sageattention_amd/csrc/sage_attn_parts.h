@@ -1,5 +1,5 @@
 // sage_attn_parts.h -- interface between the host-side dispatch of the attention launches (sage_attn.hip) and the instantiation units
-// sage_attn_d{128,64}_{f8,f8x,f16}.hip, each of which compiles the kernel family of sage_attn_kernel.h for one head size, one PV format and
+// sage_attn_d{128,64}_{f8,f8f,f16}.hip, each of which compiles the kernel family of sage_attn_kernel.h for one head size, one PV format and
 // (FP8) one score form.  The split exists for build time only: the units are independent and compile in parallel.
 #pragma once
 #include "sage_kernels.h"

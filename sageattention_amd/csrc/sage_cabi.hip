@@ -45,16 +45,20 @@ int read_attr(const SageLaunchAttr *attr, void *stream, bool takes_ws, LaunchAtt
     out.trace_wgs = 0;
     if (attr == nullptr) return SAGE_OK;
     SageLaunchAttr a{};
-    const size_t n = (attr->struct_bytes == 0 || attr->struct_bytes > sizeof(SageLaunchAttr)) ? sizeof(SageLaunchAttr) : attr->struct_bytes;
-    SAGE_REQUIRE(n >= 8, "SageLaunchAttr.struct_bytes = %u is smaller than its own header", attr->struct_bytes);
+    // struct_bytes is what the CALLER's struct holds: fewer bytes than ours (an older caller) are read as far as they go, more (a newer
+    // caller) are ignored beyond what this library knows; 0 -- a caller that never set it -- is refused rather than guessed at
+    SAGE_REQUIRE(attr->struct_bytes >= 8, "SageLaunchAttr.struct_bytes = %u: set it to sizeof(SageLaunchAttr) (at least the 8-byte header)", attr->struct_bytes);
+    const size_t n = attr->struct_bytes > sizeof(SageLaunchAttr) ? sizeof(SageLaunchAttr) : attr->struct_bytes;
     memcpy(&a, attr, n);
-    SAGE_REQUIRE((a.flags & ~(SAGE_ATTR_FP8_EXACT_SCORES | SAGE_ATTR_FORCE_PERSISTENT)) == 0, "unknown SageLaunchAttr.flags 0x%x", a.flags);
+    SAGE_REQUIRE((a.flags & ~(SAGE_ATTR_FP8_EXACT_SCORES | SAGE_ATTR_FP8_FOLDED_SCORES | SAGE_ATTR_FORCE_PERSISTENT)) == 0, "unknown SageLaunchAttr.flags 0x%x", a.flags);
+    SAGE_REQUIRE((a.flags & (SAGE_ATTR_FP8_EXACT_SCORES | SAGE_ATTR_FP8_FOLDED_SCORES)) != (SAGE_ATTR_FP8_EXACT_SCORES | SAGE_ATTR_FP8_FOLDED_SCORES),
+                 "SageLaunchAttr.flags asks for both FP8 score forms");
     SAGE_REQUIRE(a.launch_ws == nullptr || (a.launch_ws_bytes >= sage::kAttnSchedBytes && (reinterpret_cast<uintptr_t>(a.launch_ws) & 127u) == 0),
                  "the launch workspace is %d bytes, 128-byte aligned, zeroed (got %lld bytes at %p)", sage::kAttnSchedBytes,
                  (long long)a.launch_ws_bytes, a.launch_ws);
     SAGE_REQUIRE(!(a.flags & SAGE_ATTR_FORCE_PERSISTENT) || a.launch_ws != nullptr, "SAGE_ATTR_FORCE_PERSISTENT needs a launch workspace");
     out.ws = takes_ws ? static_cast<unsigned *>(a.launch_ws) : nullptr;
-    out.opts.fp8_exact = (a.flags & SAGE_ATTR_FP8_EXACT_SCORES) != 0;
+    out.opts.fp8_folded = (a.flags & SAGE_ATTR_FP8_FOLDED_SCORES) != 0;
     out.opts.force_persistent = takes_ws && (a.flags & SAGE_ATTR_FORCE_PERSISTENT) != 0;
     out.opts.grid_out = a.grid_out;
     out.trace = a.trace;

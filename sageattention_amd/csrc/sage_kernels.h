@@ -57,7 +57,7 @@ struct AttnParams {
 // launch attributes of an attention call that are not kernel parameters (the C ABI's SageLaunchAttr, include/sage_gfx950.h)
 struct AttnLaunchOpts {
     hipStream_t stream;
-    bool fp8_exact;          // FP8 PV: the exact score form (separate bias subtraction) instead of the folded one
+    bool fp8_folded;         // FP8 PV: the folded score form (opt-in variant) instead of the exact one
     bool force_persistent;   // take the ticket queues whatever the number of rounds (tests; AttnParams::sched must be set)
     int *grid_out;           // nullable (host): receives the number of workgroups launched
 };

@@ -38,19 +38,20 @@ def _lse_alloc(query: torch.Tensor, tensor_layout: int, return_lse: int) -> torc
 _PERSISTENT = os.environ.get("SAGE_PERSISTENT_LAUNCH", "1") != "0"      # 0: every attention launch leaves its order to the hardware
 # twelve rounds of the 512 workgroups an MI355X holds (the library decides; this only spares smaller calls the memset)
 _PERSISTENT_MIN_ITEMS = 6144
-# FP8 PV score form of every call that does not say otherwise: "folded" (default) or "exact" (include/sage_gfx950.h, SAGE_ATTR_FP8_EXACT_SCORES)
-_FP8_EXACT = os.environ.get("SAGE_FP8_SCORES", "folded").lower() == "exact"
+# FP8 PV score form of every call that does not say otherwise: "exact" -- the reference's formula, the default -- or the opt-in variant "folded"
+# (include/sage_gfx950.h, SAGE_ATTR_FP8_FOLDED_SCORES)
+_FP8_FOLDED = os.environ.get("SAGE_FP8_SCORES", "exact").lower() == "folded"
 
 
-def fp8_exact(kwarg=None) -> bool:
-    """``fp8_scores=`` of the FP8 entry points ("exact" / "folded" / None = the process default, SAGE_FP8_SCORES).  "folded" (3-7 % faster) is for
-    ordinary magnitudes -- its rounding error grows with c = sm_scale log2(e) q_scale k_scale, the exponent change per INT8 score step (include/sage_gfx950.h);
-    with |q|, |k| in the hundreds (c >= 0.1) ask for "exact"."""
+def fp8_folded(kwarg=None) -> bool:
+    """``fp8_scores=`` of the FP8 entry points: "exact" (the default: exp2(fma(s, c, -m)) as the reference computes it, on every input), "folded"
+    (an opt-in variant, 3-7 % faster, that rounds ``m + bias c`` once per (row, tile, k scale) -- re-rolls e4m3 roundings of P and degrades with the
+    magnitude of q and k, include/sage_gfx950.h) or None = the process default (SAGE_FP8_SCORES, "exact" unless set)."""
     if kwarg is None:
-        return _FP8_EXACT
+        return _FP8_FOLDED
     if kwarg not in ("exact", "folded"):
         raise ValueError(f"fp8_scores must be 'exact' or 'folded' (got {kwarg!r})")
-    return kwarg == "exact"
+    return kwarg == "folded"
 
 
 def attn_launch_ws(device: torch.device, is_causal, n_items: int, packed: bool = False) -> Optional[torch.Tensor]:
@@ -72,27 +73,27 @@ force_persistent = False
 trace_buf = None        # tools/attn_trace.py: an int32 CUDA tensor of 16 words per logical workgroup (read by -DSAGE_ATTN_TRACE=1 builds only)
 
 
-def attn_attr(device: torch.device, is_causal, n_items: int, exact_scores: bool = False, packed: bool = False):
+def attn_attr(device: torch.device, is_causal, n_items: int, folded_scores: bool = False, packed: bool = False):
     """The ``attr`` argument of an attention entry point for a call of ``n_items`` work items: NULL, or a ``SageLaunchAttr`` with the launch
-    workspace (``attn_launch_ws``) and / or the exact FP8 score form.  The returned object owns the workspace tensor: keep it until the C
+    workspace (``attn_launch_ws``) and / or the folded FP8 score form.  The returned object owns the workspace tensor: keep it until the C
     call has returned (the launch then runs in stream order behind the memset)."""
     ws = attn_launch_ws(device, is_causal, n_items if not force_persistent else max(n_items, _PERSISTENT_MIN_ITEMS), packed)
-    return _cabi.launch_attr(ws, exact_scores=exact_scores, force_persistent=force_persistent and ws is not None, grid_out=grid_probe,
+    return _cabi.launch_attr(ws, folded_scores=folded_scores, force_persistent=force_persistent and ws is not None, grid_out=grid_probe,
                              trace=trace_buf, trace_wgs=0 if trace_buf is None else trace_buf.numel() // 16)
 
 
 def qk_int8_sv_f8_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
                        query_scale: torch.Tensor, key_scale: torch.Tensor, value_scale: torch.Tensor,
                        value_mean: Optional[torch.Tensor], tensor_layout: int, is_causal: int, qk_quant_gran: int,
-                       q_warp: int, sm_scale_log2: float, pv_accum: int, return_lse: int, exact_scores: bool = False) -> torch.Tensor:
-    """INT8 QK^T + FP8 PV (replaces the sm89/sm90 ops, sm89_compile.py:5-146, sm90_compile.py:5-94).  ``exact_scores``: the exact FP8
-    score form instead of the folded one (a gfx950 attribute, include/sage_gfx950.h)."""
+                       q_warp: int, sm_scale_log2: float, pv_accum: int, return_lse: int, folded_scores: bool = False) -> torch.Tensor:
+    """INT8 QK^T + FP8 PV (replaces the sm89/sm90 ops, sm89_compile.py:5-146, sm90_compile.py:5-94).  ``folded_scores``: the opt-in folded
+    FP8 score form instead of the reference's exact one (a gfx950 attribute, include/sage_gfx950.h)."""
     B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(query, tensor_layout)
     _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(key, tensor_layout)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(output, tensor_layout)
     lse = _lse_alloc(query, tensor_layout, return_lse)
     code = _cabi.DTYPE_F16 if output.dtype == torch.float16 else _cabi.DTYPE_BF16
-    attr = attn_attr(query.device, is_causal, B * Hq * ((Lq + 127) // 128), exact_scores)      # (core resolves SAGE_FP8_SCORES; an explicit form wins)
+    attr = attn_attr(query.device, is_causal, B * Hq * ((Lq + 127) // 128), folded_scores)      # (core resolves SAGE_FP8_SCORES; an explicit form wins)
     rc = _cabi.load().sage_attn_qk_int8_pv_f8(
         _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
         _p(value_scale), _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
@@ -109,7 +110,7 @@ qk_int8_sv_f8_attn = torch.library.custom_op("sageattention_gfx950::qk_int8_sv_f
 
 @qk_int8_sv_f8_attn.register_fake
 def _(query, key, v_image, output, query_scale, key_scale, value_scale, value_mean, tensor_layout, is_causal,
-      qk_quant_gran, q_warp, sm_scale_log2, pv_accum, return_lse, exact_scores=False):
+      qk_quant_gran, q_warp, sm_scale_log2, pv_accum, return_lse, folded_scores=False):
     return _lse_alloc(query, tensor_layout, return_lse)
 
 

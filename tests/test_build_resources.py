@@ -40,7 +40,7 @@ def test_prepass_kernel_keeps_its_slab_in_registers():
         assert res["VGPRs"] <= 128 and res["Occupancy"] >= 4, (name, res)        # two 512-thread workgroups per CU
 
 
-ATTN_UNITS = ("sage_attn_d128_f8.hip", "sage_attn_d128_f8x.hip", "sage_attn_d128_f16.hip", "sage_attn_d64_f8.hip", "sage_attn_d64_f8x.hip",
+ATTN_UNITS = ("sage_attn_d128_f8.hip", "sage_attn_d128_f8f.hip", "sage_attn_d128_f16.hip", "sage_attn_d64_f8.hip", "sage_attn_d64_f8f.hip",
               "sage_attn_d64_f16.hip")
 
 

@@ -113,8 +113,12 @@ def test_launch_attributes_are_checked_arguments():
     assert rc == -1 and b"FORCE_PERSISTENT" in msg
     rc, msg = call(attr(struct_bytes=4))
     assert rc == -1 and b"struct_bytes" in msg
-    for ok in (attr(launch_ws=p, launch_ws_bytes=n), attr(flags=_cabi.ATTR_FP8_EXACT_SCORES), attr(struct_bytes=8),
-               attr(struct_bytes=0, launch_ws=p, launch_ws_bytes=n)):
+    rc, msg = call(attr(struct_bytes=0, launch_ws=p, launch_ws_bytes=n))     # a caller that never set it: refused, not read as a full struct
+    assert rc == -1 and b"struct_bytes" in msg
+    rc, msg = call(attr(flags=_cabi.ATTR_FP8_EXACT_SCORES | _cabi.ATTR_FP8_FOLDED_SCORES))
+    assert rc == -1 and b"both FP8 score forms" in msg
+    for ok in (attr(launch_ws=p, launch_ws_bytes=n), attr(flags=_cabi.ATTR_FP8_EXACT_SCORES), attr(flags=_cabi.ATTR_FP8_FOLDED_SCORES), attr(struct_bytes=8),
+               attr(struct_bytes=4096, launch_ws=p, launch_ws_bytes=n)):      # (a newer caller's longer struct: the bytes this library knows are read)
         rc, msg = call(ok)
         assert rc == -1 and b"divisible" in msg          # past the attribute checks
 

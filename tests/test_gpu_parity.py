@@ -27,11 +27,11 @@ if torch.cuda.is_available():
     import sageattention_amd as sa
     from sageattention_amd import _cabi, ops as sa_ops, quant as sq
     DEV = torch.device("cuda:0")
-    # the FP8 score form the product runs by default ("folded"; SAGE_FP8_SCORES=exact runs the whole suite on the exact form): every FP8
-    # comparison below is kernel(form) against oracle(SAME form) at 2e-3 * max|o|, the one rule of DESIGN.md 4
-    SCORES = "exact" if sa_ops._FP8_EXACT else "folded"
+    # the FP8 score form the product runs by default: "exact", the reference's formula (SAGE_FP8_SCORES=folded runs the whole suite on the
+    # opt-in variant against the oracle mode that mirrors it).  Every default-route comparison below is against the EXACT oracle.
+    SCORES = "folded" if sa_ops._FP8_FOLDED else "exact"
 else:
-    SCORES = "folded"
+    SCORES = "exact"
 
 REPORT = {}
 
@@ -117,7 +117,7 @@ def _check_quant_int8(oracle_mod, gran, dt, D, layout, B, Hq, Hkv, Lq, Lk, seed,
         assert (a == b).all(), f"{name}: {(a != b).sum()} mismatches of {a.size}"
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "100")))))
 def test_random_operands_bit_exact_vs_oracle(oracle_mod, seed):
     """Seeded random shapes through the operand kernels: INT8 Q / K and their scales (every granularity and rounding style), the FP8 V image
     and its per-channel scales, the FP16 V image -- every byte against the oracle."""
@@ -274,15 +274,16 @@ CASES = [
 ]
 
 
-PV_ACCUM = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f8x_two": "fp32+fp32", "f8x_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}
+PV_ACCUM = {"f8_two": "fp32+fp32", "f8_single": "fp32", "f8f_two": "fp32+fp32", "f8f_single": "fp32", "f16_two": "fp16+fp32", "f16_single": "fp32"}
 
 
 def _scores_of(pv):
-    """f8_*: FP8 PV in the product's default score form (folded); f8x_*: the exact form (fp8_scores="exact"); None for FP16 PV."""
-    return None if pv.startswith("f16") else ("exact" if pv.startswith("f8x") else "folded")
+    """f8_*: FP8 PV in the exact score form (the default); f8f_*: the opt-in folded variant (fp8_scores="folded") against the oracle mode that
+    mirrors it; None for FP16 PV (one form: exact)."""
+    return None if pv.startswith("f16") else ("folded" if pv.startswith("f8f") else "exact")
 
 
-@pytest.mark.parametrize("pv", ["f8_two", "f8_single", "f8x_two", "f8x_single", "f16_two", "f16_single"])
+@pytest.mark.parametrize("pv", ["f8_two", "f8_single", "f8f_two", "f8f_single", "f16_two", "f16_single"])
 @pytest.mark.parametrize("gran", ["per_block", "per_warp", "per_thread"])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -397,34 +398,43 @@ def degenerate_qkv(what, D):
 
 
 @pytest.mark.parametrize("what", DEGENERATE)
-@pytest.mark.parametrize("api", ["f8", "f8x", "f16", "triton"])
+@pytest.mark.parametrize("api", ["f8", "f8f", "f16", "triton", "varlen"])
 def test_degenerate_inputs_vs_oracle(oracle_mod, api, what):
     """Inputs at the edges of the quantisers.  K constant over the tokens (k - mean == 0: every k scale 0), V == 0 (every FP8 V scale 0), Q == 0, fp16 subnormals
     (x 1e-4), and magnitudes that drive c -- the exponent change per INT8 x INT8 score step, sm_scale log2(e) q_scale k_scale, 1e-4 on randn inputs -- to 5e-3
     (moderate, x 8), 0.14 (large, x 40), 90 (huge, x 1000) and 4000 (rows with one element of 30000: a q scale set by one lane).
-      * every output finite everywhere: inside the key loop P saturates like the reference's cvt.rn.satfinite (MODE.FP16_OVFL; without it the folded FP8 form
-        returned NaN rows from c ~ 0.08 on -- its m + bias c' is rounded at the magnitude of bias c' --, the exact form from c ~ 50, the FP16 loops at c ~ 50);
-      * FP8 PV, both score forms: the usual bar against the oracle in the SAME form at every c (the oracle mirrors the rounding of m + bias c' and saturates alike);
-      * FP16 PV: the usual bar up to "moderate"; the pipelined loops' folded bias has no oracle mode (general tiles use the exact form), its deviation from the exact
-        oracle grows as 2^(0.32 c): 1 % of max|o| at c = 0.14 (measured; asserted <= 3 %) -- a range where INT8 attention itself is 20 % off fp32 SDPA --,
-        unbounded beyond (huge, one_hot_rows: finite, nothing else asserted)."""
-    D = 128 if api != "triton" else 64
+    EVERY DEFAULT ROUTE -- f8 (sageattn_qk_int8_pv_fp8_cuda without fp8_scores=), f16, triton and sageattn_varlen -- is held to the usual bar,
+    2e-3 * max|o| + one output ulp, against the EXACT oracle (the reference's exp2(fma(s, c, -m)), attn_utils.cuh:445-449) on every one of these
+    inputs, outputs and LSE: since round 6 every default route evaluates that formula (rounds 4-5 folded the bias of the score's bit pattern into the
+    scale FMA, 1 % ... > 100 % of max|o| off from c ~ 0.1 on).  f8f is the opt-in folded FP8 variant against the oracle mode that mirrors it.
+    Inside the key loop P saturates like the reference's cvt.rn.satfinite (MODE.FP16_OVFL): finite outputs everywhere."""
+    D = 128 if api not in ("triton", "varlen") else 64
     q, k, v, dt = degenerate_qkv(what, D)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     km = util.bits(sq.channel_mean(kd))
     fp8 = api.startswith("f8")
-    form = "exact" if api == "f8x" else "folded"
+    form = "folded" if api == "f8f" else "exact"
     for causal in (False, True):
         if api == "triton":
             ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
                                                         qk_quant_gran="per_block", return_lse=True, km=km)
             o, lse = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, is_causal=causal, return_lse=True)
+        elif api == "varlen":
+            # the four heads' tokens as ONE packed batch of B = 1 sequence per call would hide the packed route: two sequences of unequal length
+            B, Hq, L = q.shape[0], q.shape[1], q.shape[2]
+            cut = 130
+            cu = torch.tensor([0, cut, L], dtype=torch.int32)
+            qp, kp, vp = (t[0].transpose(0, 1).contiguous() for t in (q, k, v))      # [L, H, D]
+            kmp = util.bits(_varlen_km(kp.to(DEV), cu.to(DEV), cu.to(DEV)))
+            ref = oracle_mod.sageattn_varlen(util.bits(qp), util.bits(kp), util.bits(vp), dt, cu.numpy(), cu.numpy(), is_causal=causal, km=kmp)
+            o = sa.sageattn_varlen(qp.to(DEV), kp.to(DEV), vp.to(DEV), cu.to(DEV), cu.to(DEV), L - cut, L - cut, is_causal=causal)
+            lse = lse_ref = None
         else:
             ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8" if fp8 else "f16",
                                                         qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=form)
             if fp8:
-                o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_thread", pv_accum_dtype="fp32+fp32", return_lse=True,
-                                                         fp8_scores=form)
+                kw = dict(fp8_scores="folded") if api == "f8f" else {}          # f8: the default route, no form named
+                o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_thread", pv_accum_dtype="fp32+fp32", return_lse=True, **kw)
             else:
                 o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_thread", pv_accum_dtype="fp32", return_lse=True)
         torch.cuda.synchronize()
@@ -434,12 +444,87 @@ def test_degenerate_inputs_vs_oracle(oracle_mod, api, what):
         assert np.isfinite(got).all(), tag
         scale = float(np.abs(want).max())
         err = float(np.abs(got - want).max())
-        full_bar = what in ("k_constant", "v_zero", "q_zero", "tiny", "moderate") or fp8 and what in ("large", "huge") or api == "f8x"
-        if full_bar:
-            assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{tag}: {err:.3e} vs {scale:.3e}"
-        elif what == "large":
-            assert err <= 3e-2 * scale, f"{tag}: {err:.3e} vs {scale:.3e}"
-        if what in ("k_constant", "v_zero", "q_zero", "tiny", "moderate"):
+        REPORT[f"degenerate/{api}/{what}/{'c' if causal else 'nc'}"] = dict(max_abs=err, max_o=scale)
+        assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{tag}: {err:.3e} vs {scale:.3e}"
+        if lse is not None:
+            # log2-domain maxima of 1e8 (huge) carry an fp32 ulp of 8: the bar scales with the magnitude of the LSE itself
+            lg, lr = lse.cpu().numpy(), lse_ref
+            fin = np.isfinite(lr)
+            assert (np.isfinite(lg) == fin).all(), tag
+            assert np.abs(lg[fin] - lr[fin]).max() <= 5e-3 * max(1.0, float(np.abs(lr[fin]).max()) / 64), tag
+
+
+RISING = ["randn", "ramp", "stairs", "falling", "late_spike", "early_spike"]
+
+
+def rising_qkv(what, L, D, dt=0):
+    """Score profiles along the key axis for the lazily refreshed softmax reference of the FP16-PV loops (the running maximum is refreshed, and O / l
+    rescaled, only when a row of the wave exceeds the reference by more than 8 in the log2 domain): randn (one refresh, in the first tile), a ramp of the
+    key magnitude x 1 ... x 6 (the maximum creeps up inside the window: P up to 2^8 against a stale reference), stairs (x 4 every 512 keys: jumps
+    beyond the window), falling (the first tile holds the maximum, everything later is tiny), and one key 12 x larger than the rest late / early."""
+    g = torch.Generator().manual_seed(4242 + L)
+    q = torch.randn(1, 4, L, D, generator=g)
+    k = torch.randn(1, 2, L, D, generator=g)
+    v = torch.randn(1, 2, L, D, generator=g)
+    t = torch.arange(L, dtype=torch.float32).view(1, 1, L, 1)
+    if what == "ramp":
+        k = k * (1.0 + 5.0 * t / L)
+    elif what == "stairs":
+        k = k * (4.0 ** torch.floor(t / 512.0)).clamp(max=256.0) * 0.25
+    elif what == "falling":
+        k = k * (6.0 - 5.5 * t / L)
+    elif what == "late_spike":
+        k[:, :, L - 70] *= 12.0
+    elif what == "early_spike":
+        k[:, :, 5] *= 12.0
+    dtype = torch.float16 if dt == 0 else torch.bfloat16
+    return q.to(dtype), k.to(dtype), v.to(dtype)
+
+
+@pytest.mark.parametrize("what", RISING)
+@pytest.mark.parametrize("api", ["f16", "f16_two", "triton", "varlen", "f8"])
+def test_score_profiles_along_the_key_axis_vs_oracle(oracle_mod, api, what):
+    """2048 + 90 keys (30 pipelined tiles and a ragged tail), causal and not, D = 128 and 64: the FP16-PV routes (lazy reference) and, as a control, the FP8
+    default route (reference refreshed whenever a maximum moves) against the exact oracle, which updates m in every tile as the reference's kernels do
+    (attn_utils.cuh:394-431) -- outputs at the usual bar, LSE too."""
+    L = 2138
+    for D, causal in ((128, True), (64, False), (128, False)):
+        q, k, v = rising_qkv(what, L, D)
+        dt = 0
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        km = util.bits(sq.channel_mean(kd))
+        lse = lse_ref = None
+        if api == "triton":
+            ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
+                                                        qk_quant_gran="per_block", return_lse=True, km=km)
+            o, lse = sa.sageattn_qk_int8_pv_fp16_triton(qd, kd, vd, is_causal=causal, return_lse=True)
+        elif api == "varlen":
+            cut = 700
+            cu = torch.tensor([0, cut, L], dtype=torch.int32)
+            qp, kp, vp = (t[0].transpose(0, 1).contiguous() for t in (q, k, v))
+            kmp = util.bits(_varlen_km(kp.to(DEV), cu.to(DEV), cu.to(DEV)))
+            ref = oracle_mod.sageattn_varlen(util.bits(qp), util.bits(kp), util.bits(vp), dt, cu.numpy(), cu.numpy(), is_causal=causal, km=kmp)
+            o = sa.sageattn_varlen(qp.to(DEV), kp.to(DEV), vp.to(DEV), cu.to(DEV), cu.to(DEV), L - cut, L - cut, is_causal=causal)
+        elif api == "f8":
+            ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8",
+                                                        qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=SCORES)
+            o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=causal, pv_accum_dtype="fp32+fp32", return_lse=True)
+        else:
+            two = api == "f16_two"
+            ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16",
+                                                        qk_quant_gran="per_warp" if two else "per_thread", return_lse=True, km=km,
+                                                        warpq=16 if (two and D == 128) else 32)
+            o, lse = sa.sageattn_qk_int8_pv_fp16_cuda(qd, kd, vd, is_causal=causal, qk_quant_gran="per_warp" if two else "per_thread",
+                                                      pv_accum_dtype="fp16+fp32" if two else "fp32", return_lse=True)
+        torch.cuda.synchronize()
+        got, want = o.float().cpu().numpy(), util.f32(ref, dt)
+        tag = f"{api} {what} D={D} causal={causal}"
+        assert np.isfinite(got).all(), tag
+        scale = float(np.abs(want).max())
+        err = float(np.abs(got - want).max())
+        REPORT[f"score_profiles/{api}/{what}/d{D}/{'c' if causal else 'nc'}"] = dict(max_abs=err, max_o=scale)
+        assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{tag}: {err:.3e} vs {scale:.3e}"
+        if lse is not None:
             assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3 * max(1.0, float(np.abs(lse_ref).max()) / 64), tag
 
 
@@ -485,11 +570,12 @@ FORM_CASES = [
 
 
 @pytest.mark.parametrize("case", FORM_CASES, ids=[c[0] for c in FORM_CASES])
-def test_fp8_score_forms_folded_default_vs_exact(oracle_mod, case):
-    """The folded score form is a DEFAULT FP8 route under three clauses (VERDICT r4 / DESIGN.md 4): (i) kernel(folded) meets oracle(folded) --
-    the oracle mode that mirrors it rounding for rounding -- at 2e-3 * max|o|, and kernel(exact) meets oracle(exact); (ii) folded against
-    exact: rel-RMS <= 1e-2 (kernel vs kernel here, oracle vs oracle on the CPU in tests/test_oracle_golden.py); (iii) cos / rel-RMSE vs
-    fp32 SDPA within 1e-4 / 1e-3 of the exact form's.  The exact form stays the one pinned to the reference formula."""
+def test_fp8_score_forms_exact_default_and_folded_variant(oracle_mod, case):
+    """The default FP8 route is the EXACT score form -- the one pinned to the reference's formula -- and meets the exact oracle at 2e-3 * max|o|.
+    The folded form is an opt-in variant (fp8_scores="folded") described by three measured clauses: (i) kernel(folded) meets
+    oracle(folded), the oracle mode that mirrors it rounding for rounding, at 2e-3 * max|o|; (ii) folded against exact: rel-RMS <= 1e-2 on
+    these ordinary-magnitude inputs (kernel vs kernel here, oracle vs oracle on the CPU in tests/test_oracle_golden.py); (iii) cos / rel-RMSE vs
+    fp32 SDPA within 1e-4 / 1e-3 of the exact form's."""
     name, B, Hq, Hkv, Lq, Lk, D, dt, causal, kbias = case
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=900 + Lq, kbias=kbias)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
@@ -498,7 +584,7 @@ def test_fp8_score_forms_folded_default_vs_exact(oracle_mod, case):
         out[form] = sa.sageattn(qd, kd, vd, is_causal=causal, fp8_scores=form)
     o_default = sa.sageattn(qd, kd, vd, is_causal=causal)
     torch.cuda.synchronize()
-    assert torch.equal(o_default, out[SCORES]), "the default form is the one SAGE_FP8_SCORES names (folded unless set)"
+    assert torch.equal(o_default, out[SCORES]), "the default form is the one SAGE_FP8_SCORES names (exact unless set)"
     km = util.bits(sq.channel_mean(kd))
     truth = util.sdpa_f32(q, k, v, causal).numpy()
     tn = float(np.sqrt((truth ** 2).mean()))
@@ -620,8 +706,9 @@ def test_api_accuracy_vs_sdpa(fn_name, kw, cos_min, rel_max, causal):
     truth = util.sdpa_f32(q, k, v, causal).cpu().numpy()
     got = o.float().cpu().numpy()
     cos, rel = util.cos_sim(got, truth), util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
-    REPORT[f"sdpa/{fn_name}/{kw.get('pv_accum_dtype','default')}/{'c' if causal else 'nc'}"] = dict(cos=cos, rel_rmse=rel)
+    REPORT[f"sdpa/{fn_name}/{kw.get('pv_accum_dtype','default')}/{'c' if causal else 'nc'}"] = dict(cos=cos, rel_rmse=rel, rmse=util.rmse(got, truth))
     assert cos >= cos_min and rel <= rel_max
+    assert util.rmse(got, truth) <= 5e-3            # RMSE <= 5e-3 on randn-valued inputs (absolute), both PV precisions
 
 
 def test_lse_matches_fp32_logsumexp():
@@ -727,8 +814,9 @@ def _props(fn, q, k, v, causal, tag, cos_min, rel_max):
     truth = util.sdpa_f32(q[:1, :2], k[:1, :2], v[:1, :2], causal).cpu().numpy()
     got = o_full[:1, :2].float().cpu().numpy()
     cos, rel = util.cos_sim(got, truth), util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
-    REPORT[f"full/{tag}"] = dict(cos=cos, rel_rmse=rel)
+    REPORT[f"full/{tag}"] = dict(cos=cos, rel_rmse=rel, rmse=util.rmse(got, truth))
     assert cos >= cos_min and rel <= rel_max
+    assert util.rmse(got, truth) <= 5e-3            # SURVEY 8c's absolute RMSE bar (randn inputs), as written, next to the relative one
     assert torch.isfinite(o_full.float()).all()
 
 
@@ -800,19 +888,23 @@ def test_config2_full_vs_oracle(oracle_mod):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
 
 
-def test_config3_full_vs_oracle(oracle_mod):
+@pytest.mark.parametrize("form", ["exact", "folded"])
+def test_config3_full_vs_oracle(oracle_mod, form):
     """BASELINE.json configs[2] -- the headline configuration, all 64 (batch, head) units: FP8 PV, two-level
-    accumulation, per-thread scales, bf16, B2 H32 N8192 D128 causal (the fused-Q default route)."""
+    accumulation, per-thread scales, bf16, B2 H32 N8192 D128 causal (the fused-Q default route).  exact: the default, against the exact
+    oracle (the reference's formula); folded: the opt-in variant against the oracle mode that mirrors it."""
     q, k, v = rand_qkv(2, 32, 32, 8192, 8192, 128, 1, seed=3)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=True, pv_accum_dtype="fp32+fp32", return_lse=True)
-    o_default = sa.sageattn(qd, kd, vd, is_causal=True)
+    o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=True, pv_accum_dtype="fp32+fp32", return_lse=True, fp8_scores=form)
+    if form == SCORES:
+        o_default = sa.sageattn(qd, kd, vd, is_causal=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o_default, o), "sageattn() dispatches to the FP8 two-level path in the default score form"
     torch.cuda.synchronize()
-    assert torch.equal(o_default, o), "sageattn() dispatches to the FP8 two-level path"
     km = util.bits(sq.channel_mean(kd))
     ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), 1, is_causal=True, pv="f8",
-                                                qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=SCORES)
-    _assert_vs_oracle("c3_f8pv_b2h32n8192d128_causal", o.float().cpu().numpy(), ref, 1)
+                                                qk_quant_gran="per_thread", return_lse=True, km=km, fp8_scores=form)
+    _assert_vs_oracle(f"c3_f8pv_b2h32n8192d128_causal_{form}", o.float().cpu().numpy(), ref, 1)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
 
 
@@ -843,29 +935,32 @@ def test_config4_full_vs_oracle(oracle_mod, causal):
     _assert_vs_oracle(f"c4_varlen_gqa_{'causal' if causal else 'noncausal'}", o[:, :hq].float().cpu().numpy(), ref, 1)
 
 
-def test_config5_cogvideox_shape_vs_oracle(oracle_mod):
+@pytest.mark.parametrize("form", ["exact", "folded"])
+def test_config5_cogvideox_shape_vs_oracle(oracle_mod, form):
     """BASELINE.json configs[4]: the CogVideoX1.5-shaped drop-in call, B2 H48 N=17776 (= 277*64 + 48: a
-    ragged last tile in both dimensions) D64 bf16 non-causal through sageattn(); the oracle checks eight heads of it."""
+    ragged last tile in both dimensions) D64 bf16 non-causal through sageattn(); the oracle checks eight heads of it.  exact: the default
+    route against the exact oracle; folded: the opt-in variant against the oracle mode that mirrors it."""
     B, H, N, D = 2, 48, 17776, 64
     g = torch.Generator().manual_seed(5)
     q = torch.randn(B, H, N, D, generator=g).to(torch.bfloat16)
     k = (torch.randn(B, H, N, D, generator=g) + 2.0 * torch.randn(B, H, 1, D, generator=g)).to(torch.bfloat16)
     v = torch.randn(B, H, N, D, generator=g).to(torch.bfloat16)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    o = sa.sageattn(qd, kd, vd, is_causal=False)
+    o = sa.sageattn(qd, kd, vd, is_causal=False, **({} if form == SCORES else dict(fp8_scores=form)))
     torch.cuda.synchronize()
     assert o.shape == q.shape and o.dtype == torch.bfloat16 and torch.isfinite(o.float()).all()
     hs = [0, 7, 13, 22, 31, 38, 41, 47]
     b = 1
     km = util.bits(sq.channel_mean(kd))[b:b + 1, hs]
     ref, _, _ = oracle_mod.sageattn_dense(util.bits(q[b:b + 1, hs]), util.bits(k[b:b + 1, hs]), util.bits(v[b:b + 1, hs]), 1,
-                                          is_causal=False, pv="f8", qk_quant_gran="per_thread", km=np.ascontiguousarray(km), fp8_scores=SCORES)
-    _assert_vs_oracle("c5_cogvideox_b2h48n17776d64", o[b:b + 1, hs].float().cpu().numpy(), ref, 1)
+                                          is_causal=False, pv="f8", qk_quant_gran="per_thread", km=np.ascontiguousarray(km), fp8_scores=form)
+    _assert_vs_oracle(f"c5_cogvideox_b2h48n17776d64_{form}", o[b:b + 1, hs].float().cpu().numpy(), ref, 1)
     truth = util.sdpa_f32(qd[b:b + 1, hs[:2]], kd[b:b + 1, hs[:2]], vd[b:b + 1, hs[:2]], False).cpu().numpy()
     got = o[b:b + 1, hs[:2]].float().cpu().numpy()
     cos, rel = util.cos_sim(got, truth), util.rmse(got, truth) / float(np.sqrt((truth ** 2).mean()))
-    REPORT["full/c5_cogvideox"] = dict(cos=cos, rel_rmse=rel)
+    REPORT[f"full/c5_cogvideox_{form}"] = dict(cos=cos, rel_rmse=rel, rmse=util.rmse(got, truth))
     assert cos >= 0.999 and rel <= 0.05
+    assert util.rmse(got, truth) <= 5e-3            # SURVEY 8c's absolute RMSE bar, as written
 
 
 @pytest.mark.parametrize("name", ["varlenx_nc_d128_bf16", "varlenx_c_d64_f16"])
@@ -1103,7 +1198,7 @@ def test_ring_steps_on_one_gpu_match_full_attention(causal):
 
 
 # ------------------------------------------------------------------------------------------------ randomized sweep + graphs
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))      # (SAGE_RANDOM_SEEDS=400: a one-off stress run)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "100")))))      # (SAGE_RANDOM_SEEDS=400: a one-off stress run)
 def test_random_shapes_vs_oracle(oracle_mod, seed):
     """Seeded random problems (shapes around the 64/128 tile edges and the steady/general loop boundary, GQA, both head
     dims, every granularity and accumulation mode, both layouts) against the oracle on identical operands."""
@@ -1117,7 +1212,7 @@ def test_random_shapes_vs_oracle(oracle_mod, seed):
     Lq = Lk if (causal and rng.random() < 0.7) else int(rng.integers(1, 420))
     dt = int(rng.integers(0, 2))
     gran = str(rng.choice(["per_block", "per_warp", "per_thread"]))
-    pv = str(rng.choice(["f8_two", "f8_single", "f8x_two", "f8x_single", "f16_two", "f16_single"]))
+    pv = str(rng.choice(["f8_two", "f8_single", "f8f_two", "f8f_single", "f16_two", "f16_single"]))
     layout = str(rng.choice(["HND", "NHD"]))
     q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, dt, seed=seed, kbias=float(rng.random() * 2))
     fp8 = pv.startswith("f8")
@@ -1170,7 +1265,7 @@ def test_causal_ragged_last_block_with_an_odd_count_of_pipelined_tiles(oracle_mo
         assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "24")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "100")))))
 def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     """The seeded sweep above for the entry points it does not reach: the Triton-named API (per-block scales, Q quantised in the kernel),
     sageattn_varlen (packed sequences of random lengths incl. 1-token and empty-query ones, cu_q != cu_k when not causal), the sm90 entry

@@ -78,7 +78,7 @@ def test_fused_prepass_bit_equals_the_sequence(B, H, L, D, dtype, layout, smooth
     assert int(sync.abs().sum().item()) == 0           # counters re-armed by the kernel, no give-up flag
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SAGE_RANDOM_SEEDS", "24")))))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SAGE_RANDOM_SEEDS", "100")))))
 def test_random_shapes_fused_prepass_bit_equals_the_sequence(seed):
     """Seeded random shapes (lengths around the 16-token, 64-key and 512-token slab edges, up to a dozen slabs) of the comparison above."""
     rng = np.random.default_rng(7000 + seed)

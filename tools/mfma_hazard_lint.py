@@ -22,7 +22,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sageattention_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-UNITS = ("sage_attn_d128_f8.hip", "sage_attn_d128_f8x.hip", "sage_attn_d128_f16.hip", "sage_attn_d64_f8.hip", "sage_attn_d64_f8x.hip",
+UNITS = ("sage_attn_d128_f8.hip", "sage_attn_d128_f8f.hip", "sage_attn_d128_f16.hip", "sage_attn_d64_f8.hip", "sage_attn_d64_f8f.hip",
          "sage_attn_d64_f16.hip")
 NEED = {"v_mfma_f32_32x32x64_f8f6f4": 19, "v_mfma_scale_f32_32x32x64_f8f6f4": 19}        # 16 passes; everything else used here: 8 passes
 NEED_DEFAULT = 11
