@@ -56,7 +56,11 @@ for rnd in range(4):
         torch.cuda.synchronize()
         if ref is None:
             ref = o.clone()
-        assert torch.equal(o, ref), f"{tag}: output differs from {tags[0]}"
+        if not torch.equal(o, ref):          # (SAGE_AB_ALLOW_DIFF=1: variants that are not meant to be bit-equal -- say by how much)
+            assert os.environ.get("SAGE_AB_ALLOW_DIFF") == "1", f"{tag}: output differs from {tags[0]}"
+            if rnd == 0:
+                d = (o.float() - ref.float()).abs().max().item()
+                print(f"{name} {tag}: max|o - o_{tags[0]}| = {d:.3e} at max|o| {ref.float().abs().max().item():.3e}", flush=True)
         for _ in range(8):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); step(); b.record(); b.synchronize()
@@ -64,4 +68,4 @@ for rnd in range(4):
 for tag in tags:
     xs = sorted(t[tag])
     med = xs[len(xs) // 2]
-    print(f"{name} {tag:12s} median {med:9.1f} us  best {xs[0]:9.1f} us  {fl / med / 1e6:7.1f} TFLOP/s (bit-equal to {tags[0]})", flush=True)
+    print(f"{name} {tag:12s} median {med:9.1f} us  best {xs[0]:9.1f} us  {fl / med / 1e6:7.1f} TFLOP/s", flush=True)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 6: what each gpurun call of the round ran on the GPU box (from the repo root: gpurun -- 'bash tools/r6_calls.sh callN').
+# Outputs under gpurun_out/r6<x>/; the summaries worth keeping are copied to profiles/r6_* by hand.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+filter() { grep -v "amdgpu.ids\|^  File\|^Extension\|Warning\|warnings.warn"; }
+
+call1() {   # exact-by-default build + lazy FP16 reference: the GPU suite, A/B of the FP16 routes against round 5's library and the non-lazy build, bench line
+  out=gpurun_out/r6a; mkdir -p $out
+  timeout 1700 python -m pytest tests -m gpu -q -x > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; filter < $out/pytest.log | tail -8
+  cp gpurun_out/parity_report.json $out/ 2>/dev/null
+  for t in c2 c2t c4 c4nc; do SAGE_AB_ALLOW_DIFF=1 timeout 300 python tools/lib_ab.py $t main nolazy r5 2>&1 | filter | tee -a $out/fp16_lazy_ab.txt; done
+  timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -2 $out/bench.err; cut -c1-1800 $out/bench.json
+}
+
+"$@"
