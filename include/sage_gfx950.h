@@ -278,13 +278,17 @@ SAGE_API int sage_prep_v_f16_varlen(const void *v, void *v_image, const int32_t 
  *
  *  struct_bytes     sizeof(SageLaunchAttr) as the caller compiled it (fields past it read as zero; 0 is taken as the full struct)
  *  flags            SAGE_ATTR_* below
- *  launch_ws        nullable: sage_attn_launch_ws_bytes() bytes of device memory, 128-byte aligned, ZEROED by the caller in stream order in
- *                   front of this launch, untouched until the launch has finished (then reusable, zeroed again).  With it a NON-CAUSAL,
- *                   unmasked launch of at least twelve rounds of workgroups runs as a persistent launch: as many workgroups as the device
- *                   holds at once take the work items as tickets from 32 queues (4 per XCD, own XCD first: the L2 locality of the work
- *                   order; then the fullest other queue: the XCDs of a device run a few per cent apart) -- 2.2-2.8 % faster on the CogVideoX
- *                   shape and on packed batches (profiles/r4_run_p_attention_phase_trace.txt).  Every other launch ignores it (masked and
- *                   split-KV entry points always).  A block that is NOT zero makes the launch skip work items: the contract is the caller's.
+ *  launch_ws        nullable: sage_attn_launch_ws_bytes() bytes of device memory, 128-byte aligned, ZERO when this launch starts (zeroed by the
+ *                   caller in stream order before its first use) and untouched by anyone else until the launch has finished.  A launch that
+ *                   uses it returns every word to zero before it ends (ABI 20: the last workgroup to leave re-arms the counters; ABI 19 left
+ *                   them dirty and wanted a memset per call), so ONE block per stream, zeroed once, serves every launch on that stream.
+ *                   With it a NON-CAUSAL, unmasked launch of at least twelve rounds of workgroups (and the packed route's causal launch)
+ *                   runs as a persistent launch: as many workgroups as the device holds at once take the work items as tickets from 32 queues
+ *                   (4 per XCD, own XCD first: the L2 locality of the work order; then the fullest other queue: the XCDs of a device run a few
+ *                   per cent apart) -- 2.2-2.8 % faster on the CogVideoX shape and on packed batches
+ *                   (profiles/r4_run_p_attention_phase_trace.txt).  Every other launch ignores it (masked and split-KV entry points always).
+ *                   A block that is NOT zero makes the launch skip work items: the contract is the caller's (after a launch that did not run
+ *                   to its end -- a device fault -- zero it again).
  *  launch_ws_bytes  size of that block (checked)
  *  grid_out         nullable HOST pointer: receives the number of workgroups launched (a persistent launch has fewer than work items)
  *  trace, trace_wgs debug: read by -DSAGE_ATTN_TRACE=1 builds only (tools/attn_trace.py); 16 words per logical workgroup

@@ -117,13 +117,13 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
             B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
             int(is_causal), float(sm_scale_log2), code, code, _stream(q), _cabi.attr_arg(attr))
-        _cabi.check(rc, "sage_attn_fused_q_pv_f16")
+        ops.attn_check(rc, "sage_attn_fused_q_pv_f16", attr, q.device)
         return o, lse
     rc = _cabi.load().sage_attn_fused_q_pv_f8(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_scale), _p(v_mean),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         int(is_causal), float(sm_scale_log2), code, code, _stream(q), _cabi.attr_arg(attr))
-    _cabi.check(rc, "sage_attn_fused_q_pv_f8")
+    ops.attn_check(rc, "sage_attn_fused_q_pv_f8", attr, q.device)
     return o, lse
 
 
@@ -144,7 +144,7 @@ def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         int(is_causal), float(q_premul), code, code, _stream(q), _cabi.attr_arg(attr))
-    _cabi.check(rc, "sage_attn_fused_qblock_pv_f16")
+    ops.attn_check(rc, "sage_attn_fused_qblock_pv_f16", attr, q.device)
     return o, lse
 
 
@@ -409,14 +409,14 @@ def _varlen_attend(st: _VarlenState) -> torch.Tensor:
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_ks), _p(st.order),
             _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1), st.k_int8.stride(0), st.k_int8.stride(1),
             o.stride(0), o.stride(1), int(st.is_causal), st.q_premul, code, code, _stream(o), _cabi.attr_arg(attr))
-        _cabi.check(rc, "sage_attn_fused_qblock_pv_f16_varlen")
+        ops.attn_check(rc, "sage_attn_fused_qblock_pv_f16_varlen", attr, q.device)
     else:
         rc = _cabi.load().sage_attn_qk_int8_pv_f16_varlen(
             _p(q), _p(st.k_int8), _p(st.v_image), _p(o), _p(st.q_scale), _p(st.k_scale), _p(st.cu_q), _p(st.cu_k), _p(st.cu_qs), _p(st.cu_ks),
             _p(st.order), _p(items), _p(hdr), bound, nseq, st.max_seqlen_q, Hq, Hkv, D, q.stride(0), q.stride(1),
             st.k_int8.stride(0), st.k_int8.stride(1), o.stride(0), o.stride(1), int(st.is_causal), 1.0, _cabi.PV_ACCUM_TRITON, code, _stream(o),
             _cabi.attr_arg(attr))
-        _cabi.check(rc, "sage_attn_qk_int8_pv_f16_varlen")
+        ops.attn_check(rc, "sage_attn_qk_int8_pv_f16_varlen", attr, q.device)
     return o[..., :st.head_dim_og]
 
 

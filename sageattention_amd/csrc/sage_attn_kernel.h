@@ -1462,6 +1462,21 @@ sage_attn_kernel(const AttnParams p_arg)
     bid = __builtin_amdgcn_readfirstlane(s_ticket[tpar]);      // (wave-uniform: everything derived from it stays in SGPRs)
     tpar ^= 1;
     }
+    // A persistent launch leaves its counter block as it found it: every workgroup checks out once it has no ticket left (all its ticket
+    // atomics have returned by then -- their values were consumed), and the last one to leave writes the zeros, so the caller can hand the
+    // same block to the next launch of the stream without a memset in between (round 6; the Python layer keeps one block per stream).
+    if constexpr (PERS_OK) {
+        if (pers && wave_s == 0) {
+            unsigned *const sched = kpl()->sched;
+            const int lane_x = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            unsigned gone = 0;
+            if (lane_x == 0) gone = __hip_atomic_fetch_add(sched + kAttnSchedDoneWord, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)__builtin_amdgcn_readfirstlane(gone) + 1u == gridDim.x) {
+                if (lane_x < 32) __hip_atomic_store(sched + 32 * lane_x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane_x == 32) __hip_atomic_store(sched + kAttnSchedDoneWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 

@@ -9,6 +9,7 @@ namespace sage {
 enum : int { QG_PER_BLOCK = 1, QG_PER_WARP32 = 2, QG_PER_THREAD = 3, QG_PER_WARP16 = 4, QG_PER_THREAD16 = 5 };
 
 constexpr int kAttnSchedBytes = 32 * 128;   // 32 ticket queues (8 XCDs x 4), one counter per 128-byte line
+constexpr int kAttnSchedDoneWord = 16;      // (word 16 of line 0) workgroups that have left a persistent launch: the last one returns every word to zero
 
 struct AttnParams {
     const void *q;            // int8 (or fp16 / bf16 for the fused-Q kernels), strides below (elements)
@@ -30,7 +31,7 @@ struct AttnParams {
     const int32_t *work_items;// varlen, nullable: the device-built work list of sage_varlen_plan ((sequence, query block), heaviest first)
     const int32_t *work_hdr;  // with work_items: {nitems, group, fold, left, ...} (kVarlenHdrWords)
     int items_bound;          // with work_items: host-known upper bound of nitems (sizes the grid)
-    unsigned *sched;          // persistent launch (nullable): kAttnSchedBytes of ticket counters, ZERO on entry (one counter per 128-byte line)
+    unsigned *sched;          // persistent launch (nullable): kAttnSchedBytes of ticket counters, ZERO on entry, zero again when the launch ends
     int nwg;                  // with sched: the logical grid (workgroup indices 0 .. nwg - 1 are dealt as tickets; the launch has fewer workgroups)
     int B, Hq, Hkv, group;    // group = Hq / Hkv
     int Lq, Lk;               // dense lengths; varlen: max lengths (grid sizing only)

@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from . import _cabi
+from . import _cabi, _stream_cache
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -55,31 +55,64 @@ def fp8_folded(kwarg=None) -> bool:
 
 
 def attn_launch_ws(device: torch.device, is_causal, n_items: int, packed: bool = False) -> Optional[torch.Tensor]:
-    """The launch workspace of an attention launch (``SageLaunchAttr.launch_ws``, include/sage_gfx950.h): a zeroed counter block that lets a
-    large launch run as a persistent launch over ticket queues -- NON-CAUSAL launches (2.2-2.8 % faster on the CogVideoX shape and on
+    """The launch workspace of an attention launch (``SageLaunchAttr.launch_ws``, include/sage_gfx950.h): a zero-on-entry counter block that
+    lets a large launch run as a persistent launch over ticket queues -- NON-CAUSAL launches (2.2-2.8 % faster on the CogVideoX shape and on
     packed batches) and, ``packed``, the causal launch of ``sageattn_varlen`` over its work list (+2.9 % at C4); dense causal launches
     keep the hardware's dispatch.  Results do not depend on it.  Returns the tensor or None.  ``n_items``: 128-row query blocks x heads
-    x batch of the call.  A performance attribute only: SAGE_PERSISTENT_LAUNCH=0 switches it off."""
+    x batch of the call.  The launch returns the block to zero before it ends, so it is ONE block per (device, stream), zeroed when it is
+    created (``_stream_cache``): no memset per call (rounds 4-5 allocated and zeroed a fresh one for every large call).
+    A performance attribute only: SAGE_PERSISTENT_LAUNCH=0 switches it off."""
     if (is_causal and not packed) or not _PERSISTENT or n_items < _PERSISTENT_MIN_ITEMS:
         return None
-    return torch.zeros((int(_cabi.load().sage_attn_launch_ws_bytes()) // 4,), dtype=torch.int32, device=device)
+    return _stream_cache.zeroed("attn_tickets", int(_cabi.load().sage_attn_launch_ws_bytes()) // 4, device)
 
 
-# tests / tools: a ctypes.c_int32 placed here receives the number of workgroups of every attention launch issued through attn_attr
-# (SageLaunchAttr.grid_out -- an argument of the call, the library keeps nothing); ``force`` adds SAGE_ATTR_FORCE_PERSISTENT where a
-# workspace travels along
-grid_probe = None
-force_persistent = False
-trace_buf = None        # tools/attn_trace.py: an int32 CUDA tensor of 16 words per logical workgroup (read by -DSAGE_ATTN_TRACE=1 builds only)
+class _Hooks:
+    """Test / tool hooks of the attention launches.  They are read on every launch, so they live in ONE object that is empty unless a
+    ``launch_hooks`` block is active -- not in module globals that a forgotten assignment leaves behind for every thread of the process."""
+    __slots__ = ("grid_probe", "force_persistent", "trace_buf")
+
+    def __init__(self):
+        self.grid_probe = None           # a ctypes.c_int32: receives the number of workgroups of every attention launch (SageLaunchAttr.grid_out)
+        self.force_persistent = False    # SAGE_ATTR_FORCE_PERSISTENT wherever a workspace travels along (tests: the ticket route from two rounds up)
+        self.trace_buf = None            # tools/attn_trace.py: an int32 CUDA tensor of 16 words per logical workgroup (-DSAGE_ATTN_TRACE=1 builds only)
+
+
+_hooks = _Hooks()
+
+
+class launch_hooks:
+    """``with ops.launch_hooks(grid_probe=c_int32(), force_persistent=True): ...`` -- tests and tools only.  The hooks apply to the attention
+    launches issued inside the block (by any thread: they are process-wide while active) and are gone when it exits, also on an exception."""
+
+    def __init__(self, grid_probe=None, force_persistent: bool = False, trace_buf=None):
+        self._new = (grid_probe, bool(force_persistent), trace_buf)
+
+    def __enter__(self):
+        self._old = (_hooks.grid_probe, _hooks.force_persistent, _hooks.trace_buf)
+        _hooks.grid_probe, _hooks.force_persistent, _hooks.trace_buf = self._new
+        return _hooks
+
+    def __exit__(self, *exc):
+        _hooks.grid_probe, _hooks.force_persistent, _hooks.trace_buf = self._old
+        return False
 
 
 def attn_attr(device: torch.device, is_causal, n_items: int, folded_scores: bool = False, packed: bool = False):
     """The ``attr`` argument of an attention entry point for a call of ``n_items`` work items: NULL, or a ``SageLaunchAttr`` with the launch
-    workspace (``attn_launch_ws``) and / or the folded FP8 score form.  The returned object owns the workspace tensor: keep it until the C
-    call has returned (the launch then runs in stream order behind the memset)."""
-    ws = attn_launch_ws(device, is_causal, n_items if not force_persistent else max(n_items, _PERSISTENT_MIN_ITEMS), packed)
-    return _cabi.launch_attr(ws, folded_scores=folded_scores, force_persistent=force_persistent and ws is not None, grid_out=grid_probe,
-                             trace=trace_buf, trace_wgs=0 if trace_buf is None else trace_buf.numel() // 16)
+    workspace (``attn_launch_ws``) and / or the folded FP8 score form.  The returned object references the workspace tensor: keep it until
+    the C call has returned."""
+    h = _hooks
+    ws = attn_launch_ws(device, is_causal, n_items if not h.force_persistent else max(n_items, _PERSISTENT_MIN_ITEMS), packed)
+    return _cabi.launch_attr(ws, folded_scores=folded_scores, force_persistent=h.force_persistent and ws is not None, grid_out=h.grid_probe,
+                             trace=h.trace_buf, trace_wgs=0 if h.trace_buf is None else h.trace_buf.numel() // 16)
+
+
+def attn_check(rc: int, what: str, attr, device: torch.device) -> None:
+    """``_cabi.check`` for an attention entry point; a failed call's ticket block is forgotten (it may not be zero: the next call gets a fresh one)."""
+    if rc != 0 and attr is not None and attr.launch_ws:
+        _stream_cache.drop("attn_tickets", device)
+    _cabi.check(rc, what)
 
 
 def qk_int8_sv_f8_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: torch.Tensor, output: torch.Tensor,
@@ -99,7 +132,7 @@ def qk_int8_sv_f8_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: tor
         _p(value_scale), _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
         torch._C._cuda_getCurrentRawStream(output.device.index), _cabi.attr_arg(attr))
-    _cabi.check(rc, "sage_attn_qk_int8_pv_f8")
+    attn_check(rc, "sage_attn_qk_int8_pv_f8", attr, query.device)
     return lse
 
 
@@ -130,7 +163,7 @@ def qk_int8_sv_f16_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: to
         _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
         is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
         torch._C._cuda_getCurrentRawStream(output.device.index), _cabi.attr_arg(attr))
-    _cabi.check(rc, "sage_attn_qk_int8_pv_f16")
+    attn_check(rc, "sage_attn_qk_int8_pv_f16", attr, query.device)
     return lse
 
 

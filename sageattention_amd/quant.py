@@ -21,7 +21,7 @@ from typing import NamedTuple, Optional, Tuple
 
 import torch
 
-from . import _cabi
+from . import _cabi, _stream_cache
 
 LOG2E = 1.44269504  # literal used by the reference (quant_per_block.py:87)
 
@@ -301,26 +301,11 @@ def per_channel_fp8(v: torch.Tensor, tensor_layout: str = "HND", scale_max: floa
     return v_image, v_scale, vm
 
 
-_SYNC_CACHE: dict = {}      # (device index, stream handle) -> zeroed int32 tensor
-
-
 def _prepass_sync(B: int, H: int, device) -> torch.Tensor:
     """The per-head counters of the fused pre-pass (``sync`` of ``sage_prepass_kv``): ZERO on entry, and returned to zero by the kernel
-    before it ends, so one buffer per (device, stream), zeroed ONCE when it is created, serves every call issued on that stream -- no
-    zeroing launch per call (round 5; launches on one stream run in order, launches on different streams get different buffers).  The
-    buffer is this module's, not the library's: the C ABI keeps no state.  Inside a graph capture a fresh zeroed buffer is recorded with
-    the capture instead (a captured graph must not depend on memory the cache may replace)."""
-    words = int(_cabi.load().sage_prepass_sync_words(B, H))
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros((words,), dtype=torch.int32, device=device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-    buf = _SYNC_CACHE.get(key)
-    if buf is None or buf.numel() < words:
-        if buf is None and len(_SYNC_CACHE) >= 64:         # streams come and go: the oldest entry leaves (its memory goes back to the caching
-            _SYNC_CACHE.pop(next(iter(_SYNC_CACHE)))       # allocator in the order of the stream it was allocated on, i.e. behind its last launch)
-        buf = _SYNC_CACHE[key] = torch.zeros((max(words, 4096),), dtype=torch.int32, device=device)
-    return buf
+    before it ends, so one block per (device, stream), zeroed ONCE when it is created, serves every call issued on that stream -- no
+    zeroing launch per call (``_stream_cache``: locked, dropped when a call fails or the guard trips)."""
+    return _stream_cache.zeroed("prepass", int(_cabi.load().sage_prepass_sync_words(B, H)), device, min_words=4096)
 
 
 def prepass_failed_heads(sync: torch.Tensor, B: int, H: int) -> int:
@@ -365,6 +350,7 @@ class _PrepassGuard:
         import time
         if not self.tripped and ctypes.c_int32.from_address(self.host).value != 0:
             self.tripped = True
+            _stream_cache.drop_device(self.device)      # (a give-up leaves its flag word set in the head's sync line)
             self.tripped_at = time.monotonic()
             self.trips = getattr(self, "trips", 0) + 1
             if self.trips == 1:
@@ -446,6 +432,8 @@ def prepass_kv_fp8(k: torch.Tensor, v: Optional[torch.Tensor], tensor_layout: st
     rc = lib.sage_prepass_kv(_p(k), _p(v), _p(km), _p(k_int8), _p(k_scale), _p(v_image), _p(v_scale), _p(vm), _p(ws), _p(sync),
                              B, H, L, D, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, ob, oh, ol,
                              BLKK, gran, style, float(scale_max), int(bool(v_fp16)), _dtype_code(k), _PrepassGuard.of(dev).ptr, _stream(k))
+    if rc != 0:
+        _stream_cache.drop("prepass", dev)         # (the block may not be zero any more)
     _cabi.check(rc, "sage_prepass_kv")
     if _DEBUG:
         n = prepass_failed_heads(sync, B, H)
@@ -500,6 +488,8 @@ def prepass_kv_varlen(k: torch.Tensor, v: Optional[torch.Tensor], cu_seqlens_k: 
                                     _p(plan.cu_ks), _p(plan.slab_first), _p(plan.slab_seq), _p(plan.hdr), nseq, T, int(max_seqlen_k),
                                     plan.slab_bound, H, D, k.stride(0), k.stride(1), v_sl, v_sh, k_int8.stride(0), k_int8.stride(1),
                                     _dtype_code(k), _PrepassGuard.of(dev).ptr, _stream(k))
+    if rc != 0:
+        _stream_cache.drop("prepass", dev)
     _cabi.check(rc, "sage_prepass_kv_varlen")
     if _DEBUG:
         n = prepass_failed_heads(sync, 1, H)

@@ -184,14 +184,24 @@ def varlen_cross_case(name, lens_q, lens_k, Hq, Hkv, D, dtype, causal, seed=0):
          meta=np.array([len(lens_q), Hq, Hkv, tq, tk, D, 0 if dtype == torch.float16 else 1, int(causal)], dtype=np.int64))
 
 
-def per_thread_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, seed=0):
+def per_thread_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, seed=0, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64):
+    """quant_per_thread.py:154-203 with the groups of the caller: the fp8 / fp16 CUDA APIs' default (BLKQ 128, WARPQ 32, BLKK 64, WARPK 64:
+    core.py:601-602,790-791), the fp16+fp32 API at D = 128 (WARPQ 16, core.py:604), the sm90 API (BLKQ 64, WARPQ 16, BLKK 128, WARPK 128: core.py:967)."""
     torch.manual_seed(seed)
     q = torch.randn(B, Hq, Lq, D).to(dtype)
     k = (torch.randn(B, Hkv, Lk, D) + 2.0).to(dtype)
     km = k.mean(dim=2, keepdim=True)
-    q8, qs, k8, ks = quant_pt.per_thread_int8(q, k, km, BLKQ=128, WARPQ=32, BLKK=64, WARPK=64)
+    q8, qs, k8, ks = quant_pt.per_thread_int8(q, k, km, BLKQ=BLKQ, WARPQ=WARPQ, BLKK=BLKK, WARPK=WARPK)
+    extra = {} if (BLKQ, WARPQ, BLKK, WARPK) == (128, 32, 64, 64) else dict(groups=np.array([BLKQ, WARPQ, BLKK, WARPK], dtype=np.int64))
     save(name, q=bits(q), k=bits(k), km=bits(km), q_int8=q8.numpy(), q_scale=qs.numpy(), k_int8=k8.numpy(), k_scale=ks.numpy(),
-         meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64))
+         meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64), **extra)
+
+
+def per_thread_group_cases():
+    f16, bf16 = torch.float16, torch.bfloat16
+    per_thread_case("per_thread_sm90_d128_f16", 1, 2, 1, 200, 300, 128, f16, seed=13, BLKQ=64, WARPQ=16, BLKK=128, WARPK=128)
+    per_thread_case("per_thread_sm90_d64_bf16", 2, 2, 2, 130, 129, 64, bf16, seed=14, BLKQ=64, WARPQ=16, BLKK=128, WARPK=128)
+    per_thread_case("per_thread_warpq16_d128_f16", 1, 2, 1, 200, 150, 128, f16, seed=15, BLKQ=128, WARPQ=16, BLKK=64, WARPK=64)
 
 
 if __name__ == "__main__":
@@ -204,6 +214,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--mask-skipall-only":
         mask_case("mask_bool_skipall_lq140_lk130_d64_f16", 1, 2, 1, 140, 130, 64, f16, "bool_skipall", seed=12)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--per-thread-groups-only":
+        per_thread_group_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--varlen-cross-only":
         varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
@@ -223,3 +236,4 @@ if __name__ == "__main__":
     varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
     varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
     mask_case("mask_bool_skipall_lq140_lk130_d64_f16", 1, 2, 1, 140, 130, 64, f16, "bool_skipall", seed=12)
+    per_thread_group_cases()

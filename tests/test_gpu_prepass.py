@@ -98,24 +98,33 @@ def test_random_shapes_fused_prepass_bit_equals_the_sequence(seed):
 
 
 def test_the_per_stream_sync_buffers_are_bounded():
-    """quant._prepass_sync keeps one zeroed counter buffer per (device, stream); the table is bounded (streams come and go)."""
+    """_stream_cache keeps one zeroed counter block per (purpose, device, stream); the table is bounded (streams come and go), locked, and a
+    block is forgotten when the call it was handed to fails."""
+    from sageattention_amd import _stream_cache as sc
     k, v = _mk(1, 2, 700, 64, torch.float16, "HND", 3)
     ref = quant.prepass_kv_fp8(k, v, "HND")
-    saved = dict(quant._SYNC_CACHE)
+    with sc._LOCK:
+        saved = dict(sc._CACHE)
     try:
-        for i in range(64):
-            quant._SYNC_CACHE[(0, -1 - i)] = torch.zeros((4096,), dtype=torch.int32, device="cuda")
-        full = len(quant._SYNC_CACHE)
+        with sc._LOCK:
+            for i in range(sc._MAX_ENTRIES):
+                sc._CACHE[("prepass", 0, -1 - i)] = torch.zeros((4096,), dtype=torch.int32, device="cuda")
+            full = len(sc._CACHE)
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             got = quant.prepass_kv_fp8(k, v, "HND")
+            key = sc._key("prepass", k.device)
+            assert key in sc._CACHE and int(sc._CACHE[key].abs().max().item()) == 0       # back at zero behind the launch (the .item() synchronises)
+            sc.drop("prepass", k.device)
+            assert key not in sc._CACHE
         s.synchronize()
-        assert full >= 64 and len(quant._SYNC_CACHE) <= full            # the new stream's buffer displaced the oldest entry
+        assert full >= sc._MAX_ENTRIES and len(sc._CACHE) <= full        # the new stream's block displaced the oldest entry
         for a, b, name in zip(got, ref, ("km", "k_int8", "k_scale", "v_image", "v_scale", "v_mean")):
             _same(a, b, name)
     finally:
-        quant._SYNC_CACHE.clear()
-        quant._SYNC_CACHE.update(saved)
+        with sc._LOCK:
+            sc._CACHE.clear()
+            sc._CACHE.update(saved)
 
 
 def test_triton_api_one_launch_prepass_is_bit_identical():

@@ -174,7 +174,7 @@ def test_varlen_200_launches_on_two_streams_are_bit_identical(route, causal):
 
 # ------------------------------------------------------------------------------------------------ persistent launches (ticket queues)
 # name, entry point, kwargs, (B, Hq, Hkv, Lq, Lk, D, dtype): non-causal calls of at least two rounds of workgroups (D = 128: 2 x 512 items,
-# D = 64: 2 x 768), which ops.force_persistent sends down the ticket route (SAGE_ATTR_FORCE_PERSISTENT; the default threshold is twelve
+# D = 64: 2 x 768), which ops.launch_hooks(force_persistent=True) sends down the ticket route (SAGE_ATTR_FORCE_PERSISTENT; the default threshold is twelve
 # rounds, i.e. shapes five times larger -- the same kernel, loop and queues)
 PERSISTENT_CASES = [
     ("f8_d128_fusedq_bf16", "sageattn", dict(), (1, 8, 8, 16384, 16384, 128, BF16)),
@@ -191,10 +191,9 @@ def forced_persistent(monkeypatch):
     import ctypes
     from sageattention_amd import ops
     probe = ctypes.c_int32(-1)
-    monkeypatch.setattr(ops, "grid_probe", probe)
-    monkeypatch.setattr(ops, "force_persistent", True)
     monkeypatch.setattr(ops, "_PERSISTENT", True)
-    return ops, probe
+    with ops.launch_hooks(grid_probe=probe, force_persistent=True):       # (gone when the test ends, also on a failure)
+        yield ops, probe
 
 
 def _soak(fn, want, n=None):
@@ -216,7 +215,7 @@ def _soak(fn, want, n=None):
 @pytest.mark.parametrize("case", PERSISTENT_CASES, ids=[c[0] for c in PERSISTENT_CASES])
 def test_persistent_route_200_launches_on_two_streams_equal_the_ordinary_launch(route, forced_persistent, monkeypatch, case):
     """The ticket-queue route of the large non-causal launches: 200 launches alternating between two streams beside a
-    competing GEMM, every call with a workspace of its own, each bit-identical to the ORDINARY launch of the same call; the probe confirms
+    competing GEMM, each stream with ONE self-cleaning counter block for all its launches (round 6), each bit-identical to the ORDINARY launch of the same call; the probe confirms
     that the route is really taken (fewer workgroups than work items) and really off for the reference run."""
     ops, probe = forced_persistent
     name, entry, kw, shape = case

@@ -88,6 +88,22 @@ def test_per_thread_quant_matches_reference(oracle_mod):
     assert (qs == z["q_scale"]).all() and (ks == z["k_scale"]).all()
 
 
+@pytest.mark.parametrize("name", ["per_thread_sm90_d128_f16", "per_thread_sm90_d64_bf16", "per_thread_warpq16_d128_f16"])
+def test_per_thread_quant_groups_match_reference(oracle_mod, name):
+    """The per-thread quantiser in the groups of the other callers -- the sm90 API (BLKQ 64, WARPQ 16, BLKK 128, WARPK 128: core.py:967) and the
+    fp16+fp32 API at D = 128 (WARPQ 16: core.py:604) -- against the reference's own output (quant_per_thread.py:154-203 under the interpreter):
+    every INT8 byte and every scale."""
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, _) = util.golden(name)
+    BLKQ, WARPQ, BLKK, WARPK = (int(x) for x in z["groups"])
+    gq, nq = oracle_mod.group_index(Lq, "per_thread", "q", BLKQ, WARPQ)
+    gk, nk = oracle_mod.group_index(Lk, "per_thread", "k", BLKK, WARPK)
+    q8, qs = oracle_mod.quant_int8(z["q"], dt, gq, nq, style=oracle_mod.STYLE_TRITON_THREAD)
+    k8, ks = oracle_mod.quant_int8(z["k"], dt, gk, nk, style=oracle_mod.STYLE_TRITON_THREAD, mean=np.ascontiguousarray(z["km"][:, :, 0, :]))
+    assert q8.shape == z["q_int8"].shape and qs.shape == z["q_scale"].shape and ks.shape == z["k_scale"].shape
+    assert (q8 == z["q_int8"]).all() and (k8 == z["k_int8"]).all()
+    assert (qs == z["q_scale"]).all() and (ks == z["k_scale"]).all()
+
+
 @pytest.mark.parametrize("pv,gran", [("f16_triton", "per_block"), ("f16", "per_warp"), ("f8", "per_warp"), ("f8", "per_thread"), ("f8", "per_block")])
 @pytest.mark.parametrize("causal", [False, True])
 def test_accuracy_vs_fp32_sdpa(oracle_mod, pv, gran, causal):

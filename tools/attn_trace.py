@@ -36,11 +36,11 @@ for _ in range(5):
     step()
 torch.cuda.synchronize()
 NW = 1 << 15
-sa_ops.trace_buf = torch.zeros(16 * NW, dtype=torch.int32, device=dev)
-step()
-torch.cuda.synchronize()
-buf = sa_ops.trace_buf.cpu().numpy().view(np.uint32)
-sa_ops.trace_buf = None
+tbuf = torch.zeros(16 * NW, dtype=torch.int32, device=dev)
+with sa_ops.launch_hooks(trace_buf=tbuf):
+    step()
+    torch.cuda.synchronize()
+buf = tbuf.cpu().numpy().view(np.uint32)
 if not buf.any():
     sys.exit("this library has no trace: build it with -DSAGE_ATTN_TRACE=1 and point SAGE_GFX950_LIB at it")
 t = buf.reshape(NW, 16)

@@ -16,7 +16,8 @@ from sageattention_amd import _cabi, ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda:0")
 lib = _cabi.load()
-ops.grid_probe = probe = ctypes.c_int32(-1)
+probe = ctypes.c_int32(-1)
+ops.launch_hooks(grid_probe=probe).__enter__()      # (for the life of this script)
 cases = [("c3 shape, non-causal, N=%d" % n, dict(bench.CONFIGS["c3nc"], N=n)) for n in (8192, 16384, 32768)] + [("c5", bench.CONFIGS["c5"])]
 for name, cfg in cases:
     q, k, v = bench.make_inputs(cfg, dev, 7)

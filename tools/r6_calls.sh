@@ -13,4 +13,10 @@ call1() {   # exact-by-default build + lazy FP16 reference: the GPU suite, A/B o
   timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -2 $out/bench.err; cut -c1-1800 $out/bench.json
 }
 
+call2() {   # the whole GPU suite (no -x), 100 seeds
+  out=gpurun_out/r6b; mkdir -p $out
+  timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; filter < $out/pytest.log | tail -25
+  cp gpurun_out/parity_report.json $out/ 2>/dev/null
+}
+
 "$@"
