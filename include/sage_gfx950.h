@@ -422,6 +422,26 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                                       int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                       int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
+/* The same two fused-Q FP16-PV launches with V READ IN PLACE (ABI 20): `v` is the caller's fp16 value tensor itself -- rows of D halves,
+ * last dimension contiguous, element strides v_sb / v_sh / v_sl (multiples of 8), exactly what the reference's FP16-PV ops take
+ * ("value fp16, last dim contiguous", qk_int_sv_f16_cuda_sm80.cu:693-704; the Triton forward likewise) -- instead of the gfx950 tile
+ * image.  The kernel copies 64-token tiles of rows into LDS by LDS-DMA and forms the PV operand with transposing LDS reads
+ * (ds_read_b64_tr_b16).  Bit-identical outputs to the image entry points; for fp16 inputs the V half of the pre-pass (4 of its 7 bytes per
+ * element on an FP16-PV call) is not needed at all: core.py:297-298,613's `v.to(torch.float16)` is the identity there.  fp16 q / k / v of
+ * one call only (bf16 inputs convert V, i.e. need the image pass); dense, no v_mean, no split.
+ *   _fused_q_      : per-thread q / k scale groups, CUDA kernel form (sage_attn_fused_q_pv_f16)
+ *   _fused_qblock_ : per-block groups, q_premul folded in, Triton kernel form (sage_attn_fused_qblock_pv_f16) */
+SAGE_API int sage_attn_fused_q_pv_f16_vrows(const void *q, const int8_t *k, const void *v, void *o, float *lse, const float *k_scale,
+                                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                            int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                            int is_causal, float sm_scale_log2, int out_dtype, void *stream, const SageLaunchAttr *attr);
+SAGE_API int sage_attn_fused_qblock_pv_f16_vrows(const void *q, const int8_t *k, const void *v, void *o, float *lse, const float *k_scale,
+                                                 int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                                 int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                                 int is_causal, float q_premul, int out_dtype, void *stream, const SageLaunchAttr *attr);
+
 /* The Triton-named API's attention (FP16 PV, tile product folded into the FP32 output, per-block k scales) with the PER-BLOCK Q
  * quantisation in the kernel prologue: q (fp16 / bf16) is multiplied by q_premul (= sm_scale * log2 e), one scale per 128 query rows,
  * Triton rounding -- bit-identical to sage_quant_qk_int8 (per_block, pre_scale = q_premul) + sage_attn_qk_int8_pv_f16(pv_accum =

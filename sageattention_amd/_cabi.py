@@ -102,6 +102,10 @@ SYMBOLS = {   # (the trailing _P of every sage_attn_* entry point is `const Sage
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
     "sage_attn_fused_q_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _I, _P, _P]),
+    "sage_attn_fused_q_pv_f16_vrows": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _P, _P]),
+    "sage_attn_fused_qblock_pv_f16_vrows": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                                    _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _F, _I, _P, _P]),
     "sage_varlen_plan_max_seqs": (c_int, []),
     "sage_varlen_plan": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P]),
     "sage_debug_varlen_items": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -98,11 +98,23 @@ def _attn_dense(fp8, q_int8, k_int8, v_image, v_scale, q_scale, k_scale, out_dty
     return o, (lse if return_lse else None)
 
 
+def _v_rows_ok(v, tensor_layout: str) -> bool:
+    """Whether an fp16 V tensor can be read in place by the FP16-PV kernels (``sage_attn_fused_q*_pv_f16_vrows``): 16-byte rows."""
+    if v.dtype != torch.float16 or v.stride(-1) != 1 or v.data_ptr() % 16 != 0:
+        return False
+    _, _, L, D, sb, sh, sl = _dims(v, tensor_layout)
+    return sb % 8 == 0 and sh % 8 == 0 and sl % 8 == 0 and sl >= D and ((L - 1) * sl + D) * 2 < 2 ** 31
+
+
+_V_IN_PLACE = os.environ.get("SAGE_V_IN_PLACE", "1") != "0"      # 0: fp16 inputs take the V tile image like bf16 ones (A/B, debugging)
+
+
 @torch.compiler.disable
-def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None, folded_scores=False):
+def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal, sm_scale_log2, return_lse, v_mean=None, folded_scores=False,
+                  v_rows=False):
     """FP8-PV two-level attention with the per-thread Q quantisation done in the kernel prologue
     (``sage_attn_fused_q_pv_f8``): bit-identical to ``per_thread_int8`` + the attention op, one launch and
-    3 B/element of HBM traffic less."""
+    3 B/element of HBM traffic less.  ``v_rows`` (FP16 PV): ``v_image`` is the fp16 V tensor itself, read in place."""
     B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q, tensor_layout)
     _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
     assert Hq % Hkv == 0, "num_qo_heads must be divisible by num_kv_heads"
@@ -112,6 +124,15 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
     # (a large non-causal call: persistent launch; FP8 PV: the score form)
     attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128), folded_scores and v_scale is not None)
+    if v_rows:                     # FP16 PV on fp16 inputs: V rows in place, no tile image (sage_attn_fused_q_pv_f16_vrows)
+        assert v_scale is None and v_mean is None
+        _, _, _, _, v_sb, v_sh, v_sl = _dims(v_image, tensor_layout)
+        rc = _cabi.load().sage_attn_fused_q_pv_f16_vrows(
+            _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
+            B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl,
+            int(is_causal), float(sm_scale_log2), code, _stream(q), _cabi.attr_arg(attr))
+        ops.attn_check(rc, "sage_attn_fused_q_pv_f16_vrows", attr, q.device)
+        return o, lse
     if v_scale is None:            # FP16 PV (v_image from prep_v_fp16), straight FP32 accumulation
         rc = _cabi.load().sage_attn_fused_q_pv_f16(
             _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale), _p(v_mean),
@@ -128,9 +149,10 @@ def _attn_fused_q(q, k_int8, v_image, v_scale, k_scale, tensor_layout, is_causal
 
 
 @torch.compiler.disable
-def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_premul, return_lse):
+def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_premul, return_lse, v_rows=False):
     """The Triton-named API's attention with the per-block Q quantisation in the kernel prologue
-    (``sage_attn_fused_qblock_pv_f16``): bit-identical to ``per_block_int8`` (q half) + the attention op."""
+    (``sage_attn_fused_qblock_pv_f16``): bit-identical to ``per_block_int8`` (q half) + the attention op.  ``v_rows``: ``v_image`` is the
+    fp16 V tensor itself, read in place (``sage_attn_fused_qblock_pv_f16_vrows``)."""
     q = _aligned(q, 8)
     B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(q, tensor_layout)
     _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(k_int8, tensor_layout)
@@ -140,6 +162,14 @@ def _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, q_
     lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
     code = _cabi.DTYPE_F16 if q.dtype == torch.float16 else _cabi.DTYPE_BF16
     attr = ops.attn_attr(q.device, is_causal, B * Hq * ((Lq + 127) // 128))
+    if v_rows:
+        _, _, _, _, v_sb, v_sh, v_sl = _dims(v_image, tensor_layout)
+        rc = _cabi.load().sage_attn_fused_qblock_pv_f16_vrows(
+            _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
+            B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl,
+            int(is_causal), float(q_premul), code, _stream(q), _cabi.attr_arg(attr))
+        ops.attn_check(rc, "sage_attn_fused_qblock_pv_f16_vrows", attr, q.device)
+        return o, lse
     rc = _cabi.load().sage_attn_fused_qblock_pv_f16(
         _p(q), _p(k_int8), _p(v_image), _p(o), _p(lse), _p(k_scale),
         B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
@@ -297,10 +327,16 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     torch.cuda.set_device(v.device)
     q, k, v, head_dim_og = _pad_head_dim(q, k, v)
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1, "Last dim of qkv must be contiguous."
+    # the Q half of the per-block quantiser runs in the attention kernel's prologue (same bits, no INT8 copy of Q in HBM) unless the
+    # CUDA rounding convention or a mask is asked for; fp16 inputs on that route need no V pass at all: the kernel reads V's rows in place
+    # (the reference's `v.to(torch.float16)`, core.py:297-298, is the identity for them) -- same bits as the image route
+    fuse_q = quantization_backend == "triton" and attn_mask is None and kwargs.get("fuse_q_quant", True)
+    v_rows = fuse_q and kwargs.get("v_in_place", _V_IN_PLACE) and _v_rows_ok(v, tensor_layout)
     # K mean + INT8 K (Triton rounding) + the fp16 V image as ONE launch that reads K and V once (sage_prepass_kv), when it is the faster route
     k_done = v_image = None
     if quantization_backend == "triton" and k.shape == v.shape and _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")):
-        km_s, k8, ks, v_image, _, _ = prepass_kv_fp8(k, v, tensor_layout, smooth_k=smooth_k, qk_quant_gran="per_block_triton", v_fp16=True)
+        km_s, k8, ks, v_image, _, _ = prepass_kv_fp8(k, None if v_rows else v, tensor_layout, smooth_k=smooth_k, qk_quant_gran="per_block_triton",
+                                                     v_fp16=True)
         k_done = (k8, ks)
         km, lse_correction = None, None
         if smooth_k:
@@ -315,15 +351,12 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
             "qo_len and kv_len must be equal for causal attention"
     if is_causal:
         assert attn_mask is None, "Mask should be None for causal attention."        # core.py:310
-    # the Q half of the per-block quantiser runs in the attention kernel's prologue (same bits, no INT8 copy of Q in HBM) unless the
-    # CUDA rounding convention or a mask is asked for
-    fuse_q = quantization_backend == "triton" and attn_mask is None and kwargs.get("fuse_q_quant", True)
     q_int8, q_scale, k_int8, k_scale = per_block_int8(None if fuse_q else q, k, km=km, sm_scale=sm_scale, tensor_layout=tensor_layout,
                                                       quantization_backend=quantization_backend, k_done=k_done)
-    if v_image is None:
+    if v_image is None and not v_rows:
         v_image = prep_v_fp16(v, tensor_layout)
     if fuse_q:
-        o, lse = _attn_fused_qblock(q, k_int8, v_image, k_scale, tensor_layout, is_causal, sm_scale * LOG2E, return_lse)
+        o, lse = _attn_fused_qblock(q, k_int8, v if v_rows else v_image, k_scale, tensor_layout, is_causal, sm_scale * LOG2E, return_lse, v_rows=v_rows)
     elif attn_mask is not None:
         o, lse = _attn_masked(q_int8, k_int8, v_image, q_scale, k_scale, attn_mask, dtype, tensor_layout, return_lse)
     else:
@@ -434,7 +467,7 @@ def sageattn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_
                                           kwargs))
 
 
-_ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant", "fp8_scores")
+_ROUTE_KWARGS = ("split_kv", "fused_prepass", "fuse_q_quant", "fp8_scores", "v_in_place")
 
 
 def _compiled_call(api, q, k, v, tensor_layout, is_causal, qk_quant_gran, sm_scale, pv_accum_dtype, smooth_k, smooth_v, return_lse,
@@ -549,25 +582,31 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
         smooth_v = False
     warpq = 16 if (q.size(-1) == 128 and pv_accum_dtype == "fp16+fp32") else 32              # core.py:602-604
     fused = _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass"))
-    v_in_prepass = fused and not smooth_v and k.shape == v.shape          # the fp16 image comes out of the same launch as K
+    # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM, one launch less)
+    fuse_q = qk_quant_gran == "per_thread" and pv_accum_dtype != "fp16+fp32" and kwargs.get("fuse_q_quant", _FUSE_Q16_DEFAULT)
+    n_split = 0
+    if fuse_q:
+        B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
+        n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
+    # fp16 inputs on that route: the kernel reads V's rows in place, no V image and no V half of the pre-pass (core.py:613's
+    # `v.to(torch.float16)` is the identity for them); same bits as the image route
+    v_rows = fuse_q and not n_split and not smooth_v and kwargs.get("v_in_place", _V_IN_PLACE) and _v_rows_ok(v, tensor_layout)
+    v_in_prepass = fused and not smooth_v and k.shape == v.shape and not v_rows          # the fp16 image comes out of the same launch as K
     lse_correction, _, k_int8, k_scale, v_image, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
                                                                     fused, v_fp8=False, v_fp16=v_in_prepass)
     vm = None
     if smooth_v:     # pv_accum_dtype == "fp16": sub_mean + fused v_mean epilogue (core.py:617-619)
         v_image, vm = sub_mean(v, tensor_layout)
         vm = vm.float()
-    elif not v_in_prepass:
+    elif not v_in_prepass and not v_rows:
         v_image = prep_v_fp16(v, tensor_layout)
-    if qk_quant_gran == "per_thread" and pv_accum_dtype != "fp16+fp32" and kwargs.get("fuse_q_quant", _FUSE_Q16_DEFAULT):
-        # default route: Q is quantised inside the attention kernel (same bits, no INT8 copy of Q in HBM, one launch less)
-        B_, Hq_, Lq_, _, _, _, _ = _dims(q, tensor_layout)
-        n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
+    if fuse_q:
         if n_split:
             o, lse = _attn_fused_q_split(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
                                          n_split, return_lse, v_mean=vm)
         else:
-            o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
-                                   return_lse, v_mean=vm)
+            o, lse = _attn_fused_q(_aligned(q, 8), k_int8, v if v_rows else v_image, None, k_scale, tensor_layout, is_causal, _sm_log2(sm_scale),
+                                   return_lse, v_mean=vm, v_rows=v_rows)
         return _finish(o, lse, head_dim_og, return_lse, smooth_k, lse_correction, sm_scale)
     q_int8, q_scale, gran, q_warp, sm_log2 = _quant_q(q, qk_quant_gran, tensor_layout, warpq, sm_scale)
     o, lse = _attn_dense(False, q_int8, k_int8, v_image, None, q_scale, k_scale, dtype, tensor_layout, is_causal,

@@ -67,7 +67,8 @@ hipError_t launch_attn_fused_q(const AttnParams &p_in, int head_dim, bool causal
     if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (p.cu_q != nullptr || (q_dtype != DT_F16 && q_dtype != DT_BF16)) return hipErrorInvalidValue;
-    const AttnVariant v = {causal, true, pv_fp8, 0, q_dtype == DT_F16 ? 1 : 2};
+    if (p.v_rows != 0 && (pv_fp8 || q_dtype != DT_F16 || p.kv_split > 1)) return hipErrorInvalidValue;
+    const AttnVariant v = {causal, true, pv_fp8, 0, q_dtype == DT_F16 ? 1 : 2, p.v_rows != 0};
     return launch_unit(p, head_dim, pv_fp8, v, nwork, o);
 }
 
@@ -78,7 +79,8 @@ hipError_t launch_attn_fused_qblock(const AttnParams &p_in, int head_dim, bool c
     if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (q_dtype != DT_F16 && q_dtype != DT_BF16) return hipErrorInvalidValue;
-    const AttnVariant v = {causal, false, true, 0, q_dtype == DT_F16 ? 3 : 4};
+    if (p.v_rows != 0 && (q_dtype != DT_F16 || p.cu_q != nullptr)) return hipErrorInvalidValue;
+    const AttnVariant v = {causal, false, true, 0, q_dtype == DT_F16 ? 3 : 4, p.v_rows != 0};
     return launch_unit(p, head_dim, false, v, nwork, o);
 }
 
@@ -90,7 +92,7 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
     if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0 && (pv_fp8 || causal || kthread || mask_kind < 1 || mask_kind > 3)) return hipErrorInvalidValue;
-    const AttnVariant v = {causal, kthread, mask_kind != 0 ? true : two_level, mask_kind, 0};
+    const AttnVariant v = {causal, kthread, mask_kind != 0 ? true : two_level, mask_kind, 0, false};
     return launch_unit(p, head_dim, pv_fp8, v, nwork, o);
 }
 

@@ -120,7 +120,15 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 // rounded once per (row, tile, k scale); the oracle's score_mode 1 mirrors it).  FP16-PV instantiations have one form, the exact one, and pass true.
 // CPERS: the persistent ticket loop compiled into a CAUSAL instantiation (the packed route's launches over the work list; non-causal unmasked
 // instantiations always carry it).
-template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true, bool CPERS = false>
+// VROWS (FP16 PV, dense): p.v is the caller's fp16 V tensor itself, rows of D halves with element strides p.v_sb / v_sh / v_sl -- what the
+// reference's kernels take (value fp16, last dimension contiguous: qk_int_sv_f16_cuda_sm80.cu:693-704) -- instead of the pre-transposed tile
+// image of sage_prep_v_f16 / sage_prepass_kv.  A 64-token tile lands in LDS as rows (LDS-DMA through per-lane source addresses, like K) and
+// the PV MFMA's A operand -- V^T: lane = channel, 8 tokens -- comes out of two transposing reads, ds_read_b64_tr_b16, which hand lane i of a
+// 16-lane group element (i & 3) of the four 8-byte chunks that lanes (i >> 2), 4 + (i >> 2), 8 + .., 12 + .. address
+// (tools/microbench/ubench9_tr_b16.hip, profiles/r6_run_c_ubench9_tr_b16.txt).  For fp16 inputs the V half of the pre-pass -- 2/3 of its
+// bytes on an FP16-PV call -- disappears; the outputs are bit-identical to the image route's (same operands, same MFMAs).
+template <int D, bool PV_FP8, bool CAUSAL, bool KTHREAD, bool TWO_LEVEL, int NH, int MASK = 0, int QF = 0, bool SFOLD = true, bool CPERS = false,
+          bool VROWS = false>
 __global__ void __launch_bounds__(256, SAGE_MIN_WAVES(D, MASK))
 sage_attn_kernel(const AttnParams p_arg)
 {
@@ -347,7 +355,9 @@ sage_attn_kernel(const AttnParams p_arg)
     float qsc;
     // ---- tile staging ------------------------------------------------------------------------
     const unsigned char *kbase = reinterpret_cast<const unsigned char *>(p.k) + k_off;
-    const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v);
+    static_assert(!VROWS || (!PV_FP8 && MASK == 0), "V rows in place: FP16 PV, unmasked, dense launches");
+    // (VROWS: the (batch, kv-head)'s first row; else the image array, indexed by v_tile0 + t * v_tstride)
+    const unsigned char *vbase = reinterpret_cast<const unsigned char *>(p.v) + (VROWS ? 2 * ((long)b * p.v_sb + (long)hk * p.v_sh) : 0L);
     constexpr int CPR = D / 16;                                   // 16-B chunks per K row
     // LDS-DMA: every wave-instruction moves 64 x 16 B = 1 KiB; the LDS destination is lane-linear
     // (M0 base + lane*16), so the XOR swizzle of the K image goes on the per-lane SOURCE address.
@@ -363,6 +373,38 @@ sage_attn_kernel(const AttnParams p_arg)
         const int row = e / CPR, phys = e % CPR;
         koff[i] = (unsigned)(row * (int)p.k_sl + swz_chunk<D>(row, phys) * 16);
     }
+    // VROWS: the tile in LDS is [64 tokens][D halves], at D = 128 with the 64-byte segments of a row XOR-ed by (token & 3) -- the four rows a
+    // 32-lane half of a transposing read touches then lie in different banks (unswizzled: 1.5x the read time at two workgroups per CU; D = 64
+    // measured no different).  A 1-KiB piece of the DMA is RPP whole rows; the lane's slot inside it is (row l / CPRV, chunk l % CPRV), and
+    // since RPP is a multiple of 4 the swizzle is the same for every piece: ONE per-lane source offset, piece bases in SGPRs.
+    constexpr int CPRV = D / 8;                                   // 16-B chunks per V row
+    constexpr int RPP = 64 / CPRV;                                // rows per 1-KiB piece
+    [[maybe_unused]] unsigned voffr = 0;                          // (VROWS) per-lane source offset inside a piece: row * row stride + logical chunk * 16
+    if constexpr (VROWS) {
+        const int row = lane / CPRV, phys = lane % CPRV;
+        const int logical = D == 128 ? (phys ^ ((row & 3) << 2)) : phys;
+        voffr = (unsigned)(row * (int)p.v_sl * 2 + logical * 16);
+    }
+    // the A operand of v_mfma_f32_32x32x16_f16 for channels 32 dt .. + 31 and tokens 16 c .. + 15 of the tile at LDS address `vs`: from the
+    // image one ds_read_b128 (lane = channel row of the image); from rows two transposing reads -- the lane ADDRESSES the 8-byte chunk
+    // (token 16 c + 8 half + 4 g + (s >> 2), channels 32 dt + 16 hgrp + 4 (s & 3) .. + 3), s = lane & 15, hgrp = (lane >> 4) & 1, and RECEIVES
+    // tokens 16 c + 8 half + 4 g + 0 .. 3 of channel 32 dt + (lane & 31): elements 4 half .. 4 half + 3 of the operand, the order P is in
+    auto v_frag = [&](const unsigned char *vs, int dt, int c) -> v4i {
+        if constexpr (VROWS) {
+            typedef short v4s __attribute__((ext_vector_type(4)));
+            typedef short v8s __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) v4s *lds_v4s;
+            const int s16 = lane & 15, hgrp = (lane >> 4) & 1;
+            const int seg = D == 128 ? (dt ^ (s16 >> 2)) : dt;
+            const unsigned char *a0 = vs + (16 * c + 4 * g + (s16 >> 2)) * (D * 2) + seg * 64 + 32 * hgrp + 8 * (s16 & 3);
+            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)a0);
+            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + 8 * (D * 2)));
+            return __builtin_bit_cast(v4i, (v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        } else {
+            const int drow = dt * 32 + n;
+            return *reinterpret_cast<const v4i *>(vs + drow * 128 + swz_chunk<128>(drow, 4 * g + c) * 16);
+        }
+    };
     auto issue_loads = [&](int it, int buf) {
         unsigned char *ks = smem + buf * C::STAGE_BYTES;
         unsigned char *vs = ks + C::K_TILE_BYTES;
@@ -391,12 +433,25 @@ sage_attn_kernel(const AttnParams p_arg)
         for (int hh = 0; hh < NH; hh++) {
             int tv = it * NH + hh;
             tv = tv < ntk_all ? tv : ntk_all - 1;
+            if constexpr (VROWS) {          // rows 64 tv .. of the head; rows past Lk are clamped to the last one (their probabilities are exactly zero)
+#pragma unroll
+                for (int i = 0; i < VP / 4; i++) {
+                    const int pc = wave * (VP / 4) + i;
+                    int tok = tv * BLKK + pc * RPP + lane / CPRV;
+                    tok = tok < Lk ? tok : Lk - 1;
+                    const int row = pc * RPP + lane / CPRV, phys = lane % CPRV;
+                    const int logical = D == 128 ? (phys ^ ((row & 3) << 2)) : phys;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + (long)tok * p.v_sl * 2 + logical * 16),
+                                                     (__attribute__((address_space(3))) void *)(vs + hh * C::V_IMG_BYTES + pc * 1024), 16, 0, 0);
+                }
+            } else {
             const unsigned char *vt = vbase + (v_tile0 + (long)tv * v_tstride) * (long)C::V_IMG_BYTES;
 #pragma unroll
             for (int i = 0; i < VP / 4; i++) {
                 const int pc = wave * (VP / 4) + i;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void *)(vs + hh * C::V_IMG_BYTES + pc * 1024), 16, 0, 0);
+            }
             }
         }
     };
@@ -764,7 +819,6 @@ sage_attn_kernel(const AttnParams p_arg)
                     constexpr bool FOLD = decltype(fold_tag)::value;
 #pragma unroll
                     for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
                         v16f acc;
                         if (FOLD) {
 #pragma unroll
@@ -773,10 +827,9 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                         for (int hh = 0; hh < NH; hh++) {
                             if (hh < nact) {
-                                const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 128;
 #pragma unroll
                                 for (int c = 0; c < 4; c++) {
-                                    const v8h a = *reinterpret_cast<const v8h *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                                    const v8h a = __builtin_bit_cast(v8h, v_frag(vs + hh * C::V_IMG_BYTES, dt, c));
                                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[hh][c], acc, 0, 0, 0);
                                 }
                             }
@@ -1111,7 +1164,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 static_assert(KP / 4 == 1 || KP / 4 == 2, "asm LDS-DMA: one or two K pieces per wave");
                 static_assert(VP / 4 == 2 * (KP / 4), "fp16 V image = two K tiles");
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-                const unsigned voff16 = lane * 16;
+                [[maybe_unused]] const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
                 constexpr float kLazyTau = SAGE_FP16_LAZY ? 8.0f : 0.0f;
                 float alpha_p = 1.0f;
@@ -1140,10 +1193,34 @@ sage_attn_kernel(const AttnParams p_arg)
                     __builtin_amdgcn_s_barrier();
                     {   // LDS-DMA: K(t+2) -> K region of slot nn, V(t+1) -> V region of slot nxt (SGPR-base form, see the FP8 loop)
                         const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
-                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
                         const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
                         const unsigned ldv = lds_base + nxt * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
                         unsigned keep;
+                        if constexpr (VROWS) {
+                            // V rows: piece i of the wave = rows (wave * VP / 4 + i) * RPP .. of tile it + 1; inst_offset advances the LDS address by
+                            // 1 KiB per piece and the global address with it, so every piece's SGPR base is its rows' address minus 1024 i
+                            const long ps = (long)RPP * p.v_sl * 2;
+                            const unsigned char *v0 = vbase + (long)(it + 1) * BLKK * p.v_sl * 2 + (long)wave * (VP / 4) * ps;
+                            const unsigned char *v1 = v0 + (ps - 1024);
+                            if constexpr (KP / 4 == 2) {
+                                const unsigned char *v2 = v1 + (ps - 1024), *v3 = v2 + (ps - 1024);
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                                             "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                                             "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                                             "global_load_lds_dwordx4 %6, %7\n\tglobal_load_lds_dwordx4 %6, %8 offset:1024\n\t"
+                                             "global_load_lds_dwordx4 %6, %9 offset:2048\n\tglobal_load_lds_dwordx4 %6, %10 offset:3072\n\t"
+                                             "s_mov_b32 m0, %0"
+                                             : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(ldk), "s"(ldv), "v"(voffr), "s"(v0), "s"(v1), "s"(v2), "s"(v3) : "memory");
+                            } else {
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                                             "global_load_lds_dwordx4 %1, %2\n\t"
+                                             "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                                             "global_load_lds_dwordx4 %5, %6\n\tglobal_load_lds_dwordx4 %5, %7 offset:1024\n\t"
+                                             "s_mov_b32 m0, %0"
+                                             : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(ldk), "s"(ldv), "v"(voffr), "s"(v0), "s"(v1) : "memory");
+                            }
+                        } else {
+                        const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
                         if constexpr (KP / 4 == 2)
                             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
                                          "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
@@ -1159,6 +1236,7 @@ sage_attn_kernel(const AttnParams p_arg)
                                          "global_load_lds_dwordx4 %6, %3\n\tglobal_load_lds_dwordx4 %6, %3 offset:1024\n\t"
                                          "s_mov_b32 m0, %0"
                                          : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                        }
                     }
                     float cs[2];
                     cs[0] = sm26 * (qsc * ksc[0][0]);
@@ -1166,10 +1244,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     // V fragments of tile t-1, one 32-channel tile at a time (two register sets, alternating)
                     v4i vfa[4], vfb[4];
                     auto read_v = [&](int dt, v4i (&vf)[4]) {
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vsp + drow * 128;
 #pragma unroll
-                        for (int c = 0; c < 4; c++) vf[c] = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                        for (int c = 0; c < 4; c++) vf[c] = v_frag(vsp, dt, c);
                     };
                     read_v(0, vfa);
                     A_FENCE();
@@ -1315,7 +1391,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     const int prv = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
                     const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
                     unsigned char *vsn = smem + nxt * C::STAGE_BYTES + C::K_TILE_BYTES;
-                    const unsigned char *vt = vbase + (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES;
+                    [[maybe_unused]] const unsigned char *vt = vbase + (VROWS ? 0L : (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES);
                     // V(it+1) lands in the V region of slot nxt, which held V(it-2): the tile whose fragments the LAST loop
                     // iteration read (late in its body: channel tiles 2, 3).  Every wave must be past those reads before any
                     // wave's DMA may overwrite them -- inside the loop the barrier at the top of the body orders this; here
@@ -1326,16 +1402,18 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                     for (int i = 0; i < VP / 4; i++) {
                         const int pc_ = wave * (VP / 4) + i;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc_ * 1024 + lane * 16),
-                                                         (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
+                        if constexpr (VROWS)        // (tile it + 1 is whole: the pipelined loop ends two whole tiles before the last)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + ((long)(it + 1) * BLKK + pc_ * RPP) * p.v_sl * 2 + voffr),
+                                                             (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
+                        else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc_ * 1024 + lane * 16),
+                                                             (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
                     }
 #pragma unroll
                     for (int dt = 0; dt < C::DT; dt++) {
-                        const int drow = dt * 32 + n;
-                        const unsigned char *vr = vsp + drow * 128;
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            const v4i a = *reinterpret_cast<const v4i *>(vr + swz_chunk<128>(drow, 4 * g + c) * 16);
+                            const v4i a = v_frag(vsp, dt, c);
                             A_PV16(o[dt], a, pA[c]);
                         }
                     }
@@ -1558,6 +1636,17 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
             if (v.mask_kind == 1) return launch_kernel<sage_attn_kernel<D, false, false, false, true, 1, 1>>(CM::LDS_BYTES, p, nwork, l, false);
             if (v.mask_kind == 2) return launch_kernel<sage_attn_kernel<D, false, false, false, true, 1, 2>>(CM::LDS_BYTES, p, nwork, l, false);
             if (v.mask_kind == 3) return launch_kernel<sage_attn_kernel<D, false, false, false, true, 1, 3>>(CM::LDS_BYTES, p, nwork, l, false);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (v.vrows) {                     // V rows read in place (fp16 inputs, FP16 PV, dense, fused Q quantisation): per-thread groups or per block
+        if constexpr (!PV_FP8) {
+            if (packed_list || p.cu_q != nullptr) return hipErrorInvalidValue;
+#define SAGE_VR(C_) \
+            if (v.causal == C_ && v.qf == 1) return launch_kernel<sage_attn_kernel<D, false, C_, true, false, NH, 0, 1, true, false, true>>(C::LDS_BYTES, p, nwork, l, pers); \
+            if (v.causal == C_ && v.qf == 3) return launch_kernel<sage_attn_kernel<D, false, C_, false, true, NH, 0, 3, true, false, true>>(C::LDS_BYTES, p, nwork, l, pers);
+            SAGE_VR(false) SAGE_VR(true)
+#undef SAGE_VR
         }
         return hipErrorInvalidValue;
     }

@@ -651,10 +651,15 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
                           int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                           int64_t o_sb, int64_t o_sh, int64_t o_sl,
                           int is_causal, float sm_scale_log2, int q_dtype, int out_dtype, int kv_split, void *stream, const SageLaunchAttr *attr,
-                          bool pv_fp8 = true)
+                          bool pv_fp8 = true, const int64_t *v_strides = nullptr)
 {
     LaunchAttr la;
     if (const int rc = read_attr(attr, stream, kv_split <= 1, la)) return rc;       // (split launches take no launch workspace)
+    if (v_strides != nullptr) {        // V rows in place: fp16 q / k / v tensors of one call
+        SAGE_REQUIRE(!pv_fp8 && kv_split <= 1 && q_dtype == SAGE_DTYPE_F16, "V rows in place: FP16 PV on fp16 inputs, no split");
+        SAGE_REQUIRE(v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 && v_strides[2] % 8 == 0 && v_strides[2] >= D, "v strides must be multiples of 8 elements (16-byte rows)");
+        SAGE_REQUIRE(((int64_t)(Lk - 1) * v_strides[2] + D) * 2 < (int64_t)1 << 31, "one head of v must span less than 2 GiB");
+    }
     SAGE_REQUIRE(q && k && v_image && o && k_scale && (v_scale || !pv_fp8), "null tensor pointer");
     SAGE_REQUIRE(kv_split >= 0 && (kv_split <= 1 || Hkv % kv_split == 0), "kv_split (%d) must divide the folded kv-head count (%d)", kv_split, Hkv);
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
@@ -682,6 +687,7 @@ static int fused_q_common(const void *q, const int8_t *k, const void *v_image, v
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = sm_scale_log2;
     p.kv_split = kv_split;
+    if (v_strides != nullptr) { p.v_rows = 1; p.v_sb = v_strides[0]; p.v_sh = v_strides[1]; p.v_sl = v_strides[2]; }
     return check_launch(sage::launch_attn_fused_q(p, D, is_causal != 0, q_dtype, pv_fp8, la.opts), "sage_attn_fused_q launch");
 }
 
@@ -707,6 +713,17 @@ SAGE_API int sage_attn_fused_q_pv_f16(const void *q, const int8_t *k, const void
                           o_sb, o_sh, o_sl, is_causal, sm_scale_log2, q_dtype, out_dtype, 0, stream, attr, false);
 }
 
+SAGE_API int sage_attn_fused_q_pv_f16_vrows(const void *q, const int8_t *k, const void *v, void *o, float *lse, const float *k_scale,
+                                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                            int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                            int is_causal, float sm_scale_log2, int out_dtype, void *stream, const SageLaunchAttr *attr)
+{
+    const int64_t vs[3] = {v_sb, v_sh, v_sl};
+    return fused_q_common(q, k, v, o, lse, k_scale, nullptr, nullptr, B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl,
+                          o_sb, o_sh, o_sl, is_causal, sm_scale_log2, SAGE_DTYPE_F16, out_dtype, 0, stream, attr, false, vs);
+}
+
 // q in fp16 / bf16, quantised per 128-row block in the kernel prologue (dense: cu_q == nullptr; varlen: packed tensors, B = nseq)
 static int fused_qblock_common(const void *q, const int8_t *k, const void *v_image, void *o, float *lse, const float *k_scale,
                                const int32_t *cu_q, const int32_t *cu_k, const int32_t *cu_ks, const int32_t *seq_order,
@@ -714,11 +731,17 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
                                int B, int Hq, int Hkv, int Lq, int Lk, int D,
                                int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                int64_t o_sb, int64_t o_sh, int64_t o_sl,
-                               int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr)
+                               int is_causal, float q_premul, int q_dtype, int out_dtype, void *stream, const SageLaunchAttr *attr,
+                               const int64_t *v_strides = nullptr)
 {
     LaunchAttr la;
     if (const int rc = read_attr(attr, stream, true, la)) return rc;
     const bool varlen = cu_q != nullptr;
+    if (v_strides != nullptr) {
+        SAGE_REQUIRE(!varlen && q_dtype == SAGE_DTYPE_F16, "V rows in place: dense calls on fp16 inputs");
+        SAGE_REQUIRE(v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 && v_strides[2] % 8 == 0 && v_strides[2] >= D, "v strides must be multiples of 8 elements (16-byte rows)");
+        SAGE_REQUIRE(((int64_t)(Lk - 1) * v_strides[2] + D) * 2 < (int64_t)1 << 31, "one head of v must span less than 2 GiB");
+    }
     SAGE_REQUIRE(q && k && v_image && o && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0 && (varlen || Lk > 0), "empty problem (B=%d Hq=%d Hkv=%d Lq=%d Lk=%d)", B, Hq, Hkv, Lq, Lk);
@@ -751,6 +774,7 @@ static int fused_qblock_common(const void *q, const int8_t *k, const void *v_ima
     p.out_dtype = out_dtype;
     p.sm_scale_log2 = 1.0f;                 // sm_scale * log2(e) is folded into the quantised q (q_premul), as the reference's quantiser does
     p.q_premul = q_premul;
+    if (v_strides != nullptr) { p.v_rows = 1; p.v_sb = v_strides[0]; p.v_sh = v_strides[1]; p.v_sl = v_strides[2]; }
     return check_launch(sage::launch_attn_fused_qblock(p, D, is_causal != 0, q_dtype, la.opts), "sage_attn_fused_qblock launch");
 }
 
@@ -762,6 +786,17 @@ SAGE_API int sage_attn_fused_qblock_pv_f16(const void *q, const int8_t *k, const
 {
     return fused_qblock_common(q, k, v_image, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Hq, Hkv, Lq, Lk, D,
                                q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, q_dtype, out_dtype, stream, attr);
+}
+
+SAGE_API int sage_attn_fused_qblock_pv_f16_vrows(const void *q, const int8_t *k, const void *v, void *o, float *lse, const float *k_scale,
+                                                 int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                                 int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                                 int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                                 int is_causal, float q_premul, int out_dtype, void *stream, const SageLaunchAttr *attr)
+{
+    const int64_t vs[3] = {v_sb, v_sh, v_sl};
+    return fused_qblock_common(q, k, v, o, lse, k_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, Hq, Hkv, Lq, Lk, D,
+                               q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl, is_causal, q_premul, SAGE_DTYPE_F16, out_dtype, stream, attr, vs);
 }
 
 SAGE_API int sage_attn_fused_qblock_pv_f16_varlen(const void *q, const int8_t *k, const void *v_image, void *o, const float *k_scale,

@@ -14,7 +14,9 @@ constexpr int kAttnSchedDoneWord = 16;      // (word 16 of line 0) workgroups th
 struct AttnParams {
     const void *q;            // int8 (or fp16 / bf16 for the fused-Q kernels), strides below (elements)
     const int8_t *k;
-    const void *v;            // gfx950 tiled V^T image (see sage_prep_v.hip)
+    const void *v;            // gfx950 tiled V^T image (see sage_prep_v.hip) -- or, v_rows != 0, the caller's fp16 V itself (rows of D halves)
+    long v_sb, v_sh, v_sl;    // v_rows: element strides of that tensor (batch, kv-head, token)
+    int v_rows;
     void *o;                  // fp16 / bf16
     float *lse;               // nullable, [B,Hq,Lq] log2 units
     const float *q_scale;

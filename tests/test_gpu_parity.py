@@ -541,6 +541,56 @@ def test_score_profiles_along_the_key_axis_vs_oracle(oracle_mod, api, what):
             assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3 * max(1.0, float(np.abs(lse_ref).max()) / 64), tag
 
 
+VROWS_SHAPES = [   # B, Hq, Hkv, Lq, Lk, D
+    (2, 4, 2, 300, 300, 128), (1, 3, 3, 129, 1000, 64), (1, 8, 8, 1024, 1024, 128), (2, 2, 1, 5, 70, 128), (1, 2, 2, 1, 1, 64),
+    (1, 4, 4, 2138, 2138, 128), (1, 6, 2, 640, 640, 64), (1, 2, 1, 200, 63, 128),
+]
+
+
+@pytest.mark.parametrize("shape", VROWS_SHAPES, ids=[f"b{a}h{b}k{c}q{d}l{e}d{f}" for a, b, c, d, e, f in VROWS_SHAPES])
+@pytest.mark.parametrize("layout", ["HND", "NHD"])
+@pytest.mark.parametrize("api", ["cuda", "triton"])
+def test_v_rows_in_place_is_bit_identical_to_the_tile_image_route(api, layout, shape):
+    """fp16 inputs, FP16 PV, fused Q quantisation: the attention kernel reads V's rows in place (LDS-DMA of rows + transposing LDS reads,
+    sage_attn_fused_q*_pv_f16_vrows) instead of a pre-transposed tile image.  Same operands into the same MFMAs: every output bit and every
+    LSE bit equal to the image route's, causal and not, both layouts, GQA, ragged and tiny lengths, a strided V view; and the route is really
+    taken by default (the vrows entry point is what gets called, the V image pass is not)."""
+    B, Hq, Hkv, Lq, Lk, D = shape
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, 0, seed=500 + Lq + Lk, kbias=1.0)
+    qd, kd, v0 = to_dev(q, layout), to_dev(k, layout), to_dev(v, layout)
+    # V as a view into a wider buffer (every stride doubled): rows are 16-byte aligned but not contiguous
+    wide = torch.zeros(*v0.shape[:-1], 2 * D, dtype=v0.dtype, device=DEV)
+    wide[..., D:] = v0
+    vd = wide[..., D:]
+    fn = sa.sageattn_qk_int8_pv_fp16_cuda if api == "cuda" else sa.sageattn_qk_int8_pv_fp16_triton
+    lib = _cabi.load()
+    name = "sage_attn_fused_q_pv_f16_vrows" if api == "cuda" else "sage_attn_fused_qblock_pv_f16_vrows"
+    real, calls = getattr(lib, name), []
+
+    def counting(*a):
+        calls.append(1)
+        return real(*a)
+    for causal in ((False, True) if Lq == Lk else (False,)):
+        o_img, lse_img = fn(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True, v_in_place=False)
+        setattr(lib, name, counting)
+        try:
+            o_row, lse_row = fn(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True)         # the default route
+        finally:
+            setattr(lib, name, real)
+        torch.cuda.synchronize()
+        assert len(calls) >= 1, "fp16 inputs take the V-rows route by default"
+        assert torch.equal(o_row, o_img), f"{api} {layout} {shape} causal={causal}: {(o_row.float() - o_img.float()).abs().max().item()}"
+        assert torch.equal(lse_row, lse_img)
+        calls.clear()
+    # bf16 inputs need the conversion pass: the image route, never the rows entry point
+    setattr(lib, name, counting)
+    try:
+        fn(qd.bfloat16(), kd.bfloat16(), vd.bfloat16(), tensor_layout=layout)
+    finally:
+        setattr(lib, name, real)
+    assert not calls
+
+
 def test_strided_views_of_a_packed_qkv_tensor():
     """q/k/v as non-contiguous views (the usual fused-QKV projection output): strides are honoured, no copies."""
     g = torch.Generator().manual_seed(3)

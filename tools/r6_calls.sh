@@ -19,4 +19,17 @@ call2() {   # the whole GPU suite (no -x), 100 seeds
   cp gpurun_out/parity_report.json $out/ 2>/dev/null
 }
 
+call3() {   # self-cleaning ticket counters: soak + persistence + pre-pass suites; the tr_b16 microbenchmark
+  out=gpurun_out/r6c; mkdir -p $out
+  timeout 1500 python -m pytest tests/test_gpu_soak.py tests/test_gpu_prepass.py tests/test_processors.py -m gpu -q > $out/pytest_soak.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_soak.log; filter < $out/pytest_soak.log | tail -8
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "persistent or varlen or graph or compile" > $out/pytest_pers.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_pers.log; filter < $out/pytest_pers.log | tail -8
+  if [ -x tools/microbench/ubench9 ]; then timeout 120 tools/microbench/ubench9 2>&1 | tee $out/ubench9_tr_b16.txt; fi
+}
+
+call4() {   # V rows in place: bit-identity tests, the A/B against the image route, the FP16 suites
+  out=gpurun_out/r6d; mkdir -p $out
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "v_rows or golden or degenerate or score_profiles or attention_kernel_vs_oracle or config2" > $out/pytest_vrows.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_vrows.log; filter < $out/pytest_vrows.log | tail -12
+  timeout 600 python tools/vrows_ab.py 2>&1 | filter | tee $out/vrows_ab.txt
+}
+
 "$@"
