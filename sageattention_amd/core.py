@@ -106,7 +106,25 @@ def _v_rows_ok(v, tensor_layout: str) -> bool:
     return sb % 8 == 0 and sh % 8 == 0 and sl % 8 == 0 and sl >= D and ((L - 1) * sl + D) * 2 < 2 ** 31
 
 
-_V_IN_PLACE = os.environ.get("SAGE_V_IN_PLACE", "1") != "0"      # 0: fp16 inputs take the V tile image like bf16 ones (A/B, debugging)
+_V_IN_PLACE = {"0": False, "1": True}.get(os.environ.get("SAGE_V_IN_PLACE", ""))      # 0 / 1: force the route for every eligible call (A/B, debugging)
+
+
+def _v_rows_wanted(q, k, v, tensor_layout: str, is_causal: bool, override) -> bool:
+    """Whether an FP16-PV call on fp16 inputs reads V's rows in place instead of building the tile image.  Same bits either way.  Measured
+    (profiles/r6_run_e_vrows_ab.txt, B2 H32 D128): the K-only pre-pass is 24-100 us shorter than K + V image (46 vs 72 us at N = 4096, 116 vs
+    214 at 16384: 4 of its 7 bytes per element gone), the attention kernel 2.2-3.7 % slower (twice the LDS read instructions for the V operand:
+    64-bit transposing reads); whole call + 6.5 % at C2 (N = 4096 causal), + 7-8 % at N = 2048, + 1.6-3 % at N = 4096 non-causal, 0 at N = 16384
+    causal.  The saving grows with Lk per kv-head, the loss with the (query, key) pairs per query head: rows in place up to
+    (Hq / Hkv) * Lq * (1/2 if causal) = 6144, the image beyond."""
+    if not _v_rows_ok(v, tensor_layout):
+        return False
+    if override is None:
+        override = _V_IN_PLACE
+    if override is not None:
+        return bool(override)
+    _, Hq, Lq = _dims(q, tensor_layout)[:3]
+    Hkv = _dims(k, tensor_layout)[1]
+    return (Hq // Hkv) * Lq * (0.5 if is_causal else 1.0) <= 6144
 
 
 @torch.compiler.disable
@@ -331,7 +349,7 @@ def sageattn_qk_int8_pv_fp16_triton(q, k, v, tensor_layout: str = "HND", quantiz
     # CUDA rounding convention or a mask is asked for; fp16 inputs on that route need no V pass at all: the kernel reads V's rows in place
     # (the reference's `v.to(torch.float16)`, core.py:297-298, is the identity for them) -- same bits as the image route
     fuse_q = quantization_backend == "triton" and attn_mask is None and kwargs.get("fuse_q_quant", True)
-    v_rows = fuse_q and kwargs.get("v_in_place", _V_IN_PLACE) and _v_rows_ok(v, tensor_layout)
+    v_rows = fuse_q and _v_rows_wanted(q, k, v, tensor_layout, is_causal, kwargs.get("v_in_place"))
     # K mean + INT8 K (Triton rounding) + the fp16 V image as ONE launch that reads K and V once (sage_prepass_kv), when it is the faster route
     k_done = v_image = None
     if quantization_backend == "triton" and k.shape == v.shape and _fused_prepass_wanted(k, tensor_layout, kwargs.get("fused_prepass")):
@@ -590,7 +608,7 @@ def sageattn_qk_int8_pv_fp16_cuda(q, k, v, tensor_layout: str = "HND", is_causal
         n_split = _split_kv_plan(B_, Hq_, Lq_, _dims(k, tensor_layout)[2], is_causal, kwargs.get("split_kv"))
     # fp16 inputs on that route: the kernel reads V's rows in place, no V image and no V half of the pre-pass (core.py:613's
     # `v.to(torch.float16)` is the identity for them); same bits as the image route
-    v_rows = fuse_q and not n_split and not smooth_v and kwargs.get("v_in_place", _V_IN_PLACE) and _v_rows_ok(v, tensor_layout)
+    v_rows = fuse_q and not n_split and not smooth_v and _v_rows_wanted(q, k, v, tensor_layout, is_causal, kwargs.get("v_in_place"))
     v_in_prepass = fused and not smooth_v and k.shape == v.shape and not v_rows          # the fp16 image comes out of the same launch as K
     lse_correction, _, k_int8, k_scale, v_image, _, _ = _prepass_kv(q, k, v, tensor_layout, qk_quant_gran, 64, smooth_k, False, return_lse,
                                                                     fused, v_fp8=False, v_fp16=v_in_prepass)

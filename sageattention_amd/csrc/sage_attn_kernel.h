@@ -389,16 +389,24 @@ sage_attn_kernel(const AttnParams p_arg)
     // image one ds_read_b128 (lane = channel row of the image); from rows two transposing reads -- the lane ADDRESSES the 8-byte chunk
     // (token 16 c + 8 half + 4 g + (s >> 2), channels 32 dt + 16 hgrp + 4 (s & 3) .. + 3), s = lane & 15, hgrp = (lane >> 4) & 1, and RECEIVES
     // tokens 16 c + 8 half + 4 g + 0 .. 3 of channel 32 dt + (lane & 31): elements 4 half .. 4 half + 3 of the operand, the order P is in
+    // (the lane's part of the address is loop-invariant -- one offset per 32-channel tile at D = 128, where the segment swizzle depends on dt -- and
+    //  the (c, half) part an immediate: one address add per channel tile and 64-key tile, in the LDS address space so that the offsets fold)
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
+    [[maybe_unused]] int vr_off[C::DT];
+    if constexpr (VROWS) {
+        const int s16 = lane & 15, hgrp = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; dt++)
+            vr_off[dt] = (4 * g + (s16 >> 2)) * (D * 2) + (D == 128 ? (dt ^ (s16 >> 2)) : dt) * 64 + 32 * hgrp + 8 * (s16 & 3);
+    }
     auto v_frag = [&](const unsigned char *vs, int dt, int c) -> v4i {
         if constexpr (VROWS) {
             typedef short v4s __attribute__((ext_vector_type(4)));
             typedef short v8s __attribute__((ext_vector_type(8)));
             typedef __attribute__((address_space(3))) v4s *lds_v4s;
-            const int s16 = lane & 15, hgrp = (lane >> 4) & 1;
-            const int seg = D == 128 ? (dt ^ (s16 >> 2)) : dt;
-            const unsigned char *a0 = vs + (16 * c + 4 * g + (s16 >> 2)) * (D * 2) + seg * 64 + 32 * hgrp + 8 * (s16 & 3);
-            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)a0);
-            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + 8 * (D * 2)));
+            const lds_bytes a0 = (lds_bytes)vs + vr_off[dt];
+            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + 16 * c * (D * 2)));
+            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + (16 * c + 8) * (D * 2)));
             return __builtin_bit_cast(v4i, (v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         } else {
             const int drow = dt * 32 + n;

@@ -574,7 +574,7 @@ def test_v_rows_in_place_is_bit_identical_to_the_tile_image_route(api, layout, s
         o_img, lse_img = fn(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True, v_in_place=False)
         setattr(lib, name, counting)
         try:
-            o_row, lse_row = fn(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True)         # the default route
+            o_row, lse_row = fn(qd, kd, vd, tensor_layout=layout, is_causal=causal, return_lse=True)         # the default route (these sizes: rows)
         finally:
             setattr(lib, name, real)
         torch.cuda.synchronize()

@@ -32,4 +32,10 @@ call4() {   # V rows in place: bit-identity tests, the A/B against the image rou
   timeout 600 python tools/vrows_ab.py 2>&1 | filter | tee $out/vrows_ab.txt
 }
 
+call5() {   # V rows, second take (operand addresses as immediates): bit-identity tests + A/B
+  out=gpurun_out/r6e; mkdir -p $out
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "v_rows" > $out/pytest_vrows.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_vrows.log; filter < $out/pytest_vrows.log | tail -5
+  timeout 600 python tools/vrows_ab.py c2 c2nc c2l n2k 2>&1 | filter | tee $out/vrows_ab.txt
+}
+
 "$@"
