@@ -74,13 +74,13 @@ CONFIGS = {
 # instruction the PV step issues; the non-scaled fp8 MFMA runs at the bf16 rate), int8 = 2x bf16 = 5.0 POPS.
 # Half of the FLOPs are INT8 (QK^T), half FP8 or FP16 (PV) -> harmonic blend:
 PEAK_I8, PEAK_F8, PEAK_F16 = 5000.0, 5000.0, 2500.0
-# HBM-side bytes per launch of the dominant kernels: read from profiles/r5_pmc.json, the summary tools/pmc_collect.py wrote from rocprofv3 --pmc
+# HBM-side bytes per launch of the dominant kernels: read from profiles/r6_pmc.json, the summary tools/pmc_collect.py wrote from rocprofv3 --pmc
 # passes at the commit named inside it ((2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB; FETCH_SIZE and WRITE_SIZE in passes of their own; the gfx950
 # correction per MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide streaming reads).  One entry per driver-run configuration;
-# profiles/r5_pmc_<cfg>.txt holds the raw counters and the other derived figures (VALU-active, MFMA-busy, waves per SIMD, LDS conflicts).
+# profiles/r6_pmc_<cfg>.txt holds the raw counters and the other derived figures (VALU-active, MFMA-busy, waves per SIMD, LDS conflicts).
 # algorithmic bytes: INT8 q (kernel-only bench) + 16-bit o + INT8 k + FP8 / FP16 V image; c4 / c2t: 16-bit q (quantised in the prologue)
 ALGO_BYTES = {"c3": 335.5e6, "c5": 546.1e6, "c2": 201.3e6, "c4": 651.9e6, "c4nc": 651.9e6, "c2t": 268.4e6}
-_PMC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_pmc.json")
+_PMC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6_pmc.json")
 try:
     PMC = json.load(open(_PMC_PATH))
 except Exception:          # (a checkout without the profile: traffic is reported as null, never as a stale constant)
@@ -93,7 +93,7 @@ def pmc_traffic(config_name):
     if not e:
         return None, None
     return float(e["traffic_bytes"]), ("rocprofv3 --pmc passes at commit %s, %s: (2 x FETCH_SIZE %.0f + WRITE_SIZE %.0f) KiB; algorithmic %.4g B (x %.2f)"
-                                       % (e.get("commit", "?"), e.get("file", "profiles/r5_pmc.json"), e["fetch_kib"], e["write_kib"],
+                                       % (e.get("commit", "?"), e.get("file", "profiles/r6_pmc.json"), e["fetch_kib"], e["write_kib"],
                                           e["algorithmic_bytes"], e["traffic_over_algorithmic"]))
 
 
@@ -430,11 +430,26 @@ def measure_dense(name, cfg, device, steps, warmup, ramp, with_e2e=True):
     if cfg["pv"] == "fp8":
         out["fp8_score_form"] = _score_form()
         out["fp8_folded_variant"] = folded_variant(cfg, ops, fl, max(5, steps // 2), 3, ramp)
+    if cfg["pv"] == "fp16" and q.dtype == torch.float16:
+        # the attention launch of the DEFAULT route of sageattn_qk_int8_pv_fp16_cuda on fp16 inputs at this size: Q quantised in the prologue, V rows
+        # read in place (no tile image; bit-identical outputs) -- beside the reference-style number above (INT8 operands + image)
+        from sageattention_amd import core
+        q8, qs, k8, ks, vimg, vscale, gran, q_warp, sm_log2 = ops
+        rows = core._v_rows_wanted(q, k, v, "HND", cfg["causal"], None)
+        _, d = timed(lambda: core._attn_fused_q(q, k8, v if rows else vimg, None, ks, "HND", cfg["causal"], sm_log2, False, v_rows=rows), max(5, steps // 2), 3, False, ramp)
+        ms = sum(d) / len(d)
+        out["kernel_only_default_route"] = {"ms_per_launch": round(ms, 4), "tflops": round(fl / ms / 1e9, 2),
+                                            "what": "fused per-thread Q quantisation" + (" + V rows in place (sage_attn_fused_q_pv_f16_vrows)" if rows else " + V tile image")}
     if with_e2e:
         n = max(3, steps // 2)
         wall, _ = timed(lambda: e2e_step(cfg, q, k, v), n, 2, False, ramp)
         out["end_to_end"] = {"ms_per_call": round(wall / n * 1e3, 4), "tflops": round(fl / (wall / n) / 1e12, 2),
                              "what": "whole call: K mean + INT8 Q/K quant + V pre-pass + attention"}
+        if cfg["pv"] == "fp16" and q.dtype == torch.float16:
+            import sageattention_amd as sa
+            wall, _ = timed(lambda: sa.sageattn_qk_int8_pv_fp16_cuda(q, k, v, is_causal=cfg["causal"], pv_accum_dtype="fp32", v_in_place=False), n, 2, False, ramp)
+            out["end_to_end_v_image_route"] = {"ms_per_call": round(wall / n * 1e3, 4), "tflops": round(fl / (wall / n) / 1e12, 2),
+                                               "what": "the same call with v_in_place=False: K + V tile image pre-pass (what bf16 inputs take)"}
     return out, (q, k, v)
 
 
@@ -447,13 +462,15 @@ def measure_triton_api(cfg, q, k, v, steps, warmup, ramp):
     fl = flops(cfg)
     sm = cfg["D"] ** -0.5
     _, k8, ks, vimg, _, _ = sq.prepass_kv_fp8(k, v, "HND", smooth_k=True, qk_quant_gran="per_block_triton", v_fp16=True)
-    _, dev_k = timed(lambda: core._attn_fused_qblock(q, k8, vimg, ks, "HND", cfg["causal"], sm * 1.44269504, False), steps, warmup, False, ramp)
+    rows = core._v_rows_wanted(q, k, v, "HND", cfg["causal"], None)       # (fp16 inputs at this size: V rows in place, the call's default route)
+    _, dev_k = timed(lambda: core._attn_fused_qblock(q, k8, v if rows else vimg, ks, "HND", cfg["causal"], sm * 1.44269504, False, v_rows=rows),
+                     steps, warmup, False, ramp)
     kern_ms = sum(dev_k) / len(dev_k)
     n = max(3, steps // 2)
     wall, _ = timed(lambda: sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, is_causal=cfg["causal"]), n, 2, False, ramp)
     return {"workload": "sageattn_qk_int8_pv_fp16_triton at the C2 shape (B=2 H=32 N=4096 D=128 causal, fp16)",
             "kernel_only": {"ms_per_launch": round(kern_ms, 4), "tflops": round(fl / kern_ms / 1e9, 2)},
-            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (per-block Q quantised in the prologue, Triton kernel form)", "c2t"),
+            "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (per-block Q quantised in the prologue, Triton kernel form" + (", V rows in place)" if rows else ")"), "c2t"),
             "end_to_end": {"ms_per_call": round(wall / n * 1e3, 4), "tflops": round(fl / (wall / n) / 1e12, 2)}}
 
 
@@ -507,6 +524,20 @@ def other_configs(args, device):
                     "ms_per_call": round(wall / (layers * dsteps) * 1e3, 4), "tflops": round(flops(CONFIGS["c5"]) * layers * dsteps / wall / 1e12, 2)}
     out["c5"] = c5
     del q, k, v
+    # a decode / cross-attention-like call (few query rows, long KV): 32 workgroups on a 256-CU part unless the key range is split.  FP8 split-KV
+    # rounds every P against a per-chunk maximum -- 2.8e-2 rel-RMS from the unsplit result, not the reference's arithmetic -- so it is opt-in
+    # (split_kv="auto"); the FP16-PV entry point, whose split result meets the unsplit oracle at the usual bar, plans it by itself
+    import sageattention_amd as sa
+    g = torch.Generator(device="cpu").manual_seed(5)
+    qd = torch.randn(1, 32, 128, 128, generator=g).to(torch.bfloat16).to(device)
+    kd, vd = (torch.randn(1, 32, 32768, 128, generator=g).to(torch.bfloat16).to(device) for _ in range(2))
+    dec = {"workload": "B=1 H=32 Lq=128 Lk=32768 D=128 non-causal, bf16, whole calls (pre-pass of 32768 keys included)"}
+    for label, fn in (("fp8_default_unsplit", lambda: sa.sageattn(qd, kd, vd)), ("fp8_split_kv_auto_opt_in", lambda: sa.sageattn(qd, kd, vd, split_kv="auto")),
+                      ("fp16_pv_default_auto_split", lambda: sa.sageattn_qk_int8_pv_fp16_cuda(qd, kd, vd))):
+        wall, _ = timed(fn, 10, 3, False, 0.0)
+        dec[label] = {"us_per_call": round(wall / 10 * 1e6, 1)}
+    out["decode_like"] = dec
+    del qd, kd, vd
     # the reference bench script's own shape: batch 4, per_warp (sm90 groups), N = 1k .. 32k, causal and non-causal, kernel-only
     sw = {"what": "kernel-only TFLOP/s, batch 4, H=32, D=128, qk_quant_gran per_warp in the sm90 kernels' groups (q per 16 rows, k per 128 keys), "
                   "fp32+fp32 -- bench/bench_qk_int8_pv_fp8_cuda_sm90.py:7-11,33-50; median of 20 launches each (10 at N = 32k), HIP events",

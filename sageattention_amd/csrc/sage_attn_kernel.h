@@ -1139,9 +1139,8 @@ sage_attn_kernel(const AttnParams p_arg)
             //    registers in 60-85 % of the tiles of a C2 block (some row of 32 sets a record), here once or twice per work item.  FP8 PV
             //    cannot do this: e4m3's 2^-4 rounding of P is re-rolled by any change of the reference.
             //    The scores themselves take the exact form fma(s, c, -m) (SAGE_SCALE2_EXACT), as the reference's (attn_utils.cuh:445-449).
-#ifndef SAGE_FP16_LAZY       // A/B of round 6: 0 = refresh whenever a maximum of the wave moves (rounds 2-5)
-#define SAGE_FP16_LAZY 1
-#endif
+            //    Measured (profiles/r6_run_a_fp16_exact_lazy_ab.txt): exact scores cost the FP16 routes 4-5 % against round 5's folded bias, the lazy
+            //    reference returns it (C2 -0.8 %, C4 causal +1.2 % against round 5; +4.2 % / +4.5 % against exact scores refreshed on every move).
 #define SAGE_SCALE2 SAGE_SCALE2_EXACT
 #define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
@@ -1174,7 +1173,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
                 [[maybe_unused]] const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
-                constexpr float kLazyTau = SAGE_FP16_LAZY ? 8.0f : 0.0f;
+                constexpr float kLazyTau = 8.0f;
                 float alpha_p = 1.0f;
                 bool moved_p = false;              // wave-uniform: the previous tile refreshed the reference, O owes alpha_p
                 auto rescale = [&]() {

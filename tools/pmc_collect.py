@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Round-5 PMC evidence at HEAD: one set of rocprofv3 --pmc passes per dominant kernel instantiation, summarised with ONE formula per
-derived figure into gpurun_out/<tag>/r5_pmc_<cfg>.txt and gpurun_out/<tag>/r5_pmc.json (copied to profiles/ and read by bench.py).
+"""PMC evidence at HEAD (rounds 5-6; ROUND below names the output files): one set of rocprofv3 --pmc passes per dominant kernel instantiation, summarised with ONE formula per
+derived figure into gpurun_out/<tag>/r6_pmc_<cfg>.txt and gpurun_out/<tag>/r6_pmc.json (copied to profiles/ and read by bench.py).
 
 Passes per configuration (a process each; counters only, no trace domain beside --pmc):
   A  GRBM_GUI_ACTIVE + 8 SQ slots   time base, resident waves, VALU-active, MFMA-busy, waits
@@ -21,6 +21,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = "r6"
 GROUPS = {
     "A": "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES",
     "B": "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS",
@@ -28,12 +29,15 @@ GROUPS = {
     "W": "WRITE_SIZE",
 }
 TARGETS = {   # cfg -> (command, kernel-name filter, what it is, algorithmic bytes per launch)
-    "c3": (["tools/run_kernel.py", "c3", "3"], "sage_attn_kernel", "C3 attention kernel (B2 H32 N8192 D128 causal, INT8-q per-thread, FP8 PV two-level, folded scores)", 335.5e6),
-    "c2": (["tools/run_kernel.py", "c2", "3"], "sage_attn_kernel", "C2 attention kernel (B2 H32 N4096 D128 causal, INT8-q per-thread, FP16 PV)", 201.3e6),
+    "c3": (["tools/run_kernel.py", "c3", "3"], "sage_attn_kernel", "C3 attention kernel (B2 H32 N8192 D128 causal, INT8-q per-thread, FP8 PV two-level, exact scores: the default)", 335.5e6),
+    "c2": (["tools/run_kernel.py", "c2", "3"], "sage_attn_kernel", "C2 attention kernel (B2 H32 N4096 D128 causal, INT8-q per-thread, FP16 PV: exact scores, lazily refreshed reference)", 201.3e6),
     "c2t": (["tools/run_kernel.py", "c2t", "3"], "sage_attn_kernel", "Triton-named API at the C2 shape: attention kernel with the per-block Q quantiser in its prologue (fp16 q read: 2 B/elt)", 268.4e6),
     "c4": (["tools/run_kernel.py", "c4", "3"], "sage_attn_kernel", "C4 causal packed attention launch over the work list (persistent since round 5)", 651.9e6),
     "c4nc": (["tools/run_kernel.py", "c4nc", "3"], "sage_attn_kernel", "C4 non-causal packed attention launch over the work list (persistent)", 651.9e6),
-    "c5": (["tools/run_kernel.py", "c5", "3"], "sage_attn_kernel", "C5 attention kernel (B2 H48 N17776 D64 non-causal, persistent launch, folded scores)", 546.1e6),
+    "c5": (["tools/run_kernel.py", "c5", "3"], "sage_attn_kernel", "C5 attention kernel (B2 H48 N17776 D64 non-causal, persistent launch, exact scores: the default)", 546.1e6),
+    "c3f": (["tools/run_kernel.py", "c3", "3", "folded"], "sage_attn_kernel", "C3 attention kernel, the opt-in FOLDED score variant (fp8_scores=\"folded\")", 335.5e6),
+    "c5f": (["tools/run_kernel.py", "c5", "3", "folded"], "sage_attn_kernel", "C5 attention kernel, the opt-in FOLDED score variant", 546.1e6),
+    "c2r": (["tools/run_kernel.py", "c2r", "3"], "sage_attn_kernel", "C2 default route on fp16 inputs: fused per-thread Q quantisation + V rows in place (fp16 q and v read: 2 B/elt each)", 335.5e6),
     "pp": (["tools/run_prepass.py", "fused", "2,32,8192,128", "3"], "prepass_kv_kernel", "one-launch K / V pre-pass at the C3 shape (Infinity Cache flushed between launches)", 402.7e6),
 }
 
@@ -101,7 +105,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or os.environ.get("SAGE_HEAD", "?")
-    jpath = os.path.join(out, "r5_pmc.json")
+    jpath = os.path.join(out, f"{ROUND}_pmc.json")
     allj = json.load(open(jpath)) if os.path.exists(jpath) else {}
     for cfg in cfgs:
         raw = {}
@@ -111,11 +115,11 @@ def main():
             print(f"{cfg}: passes incomplete ({sorted(raw)})", flush=True)
             continue
         d = summarise(cfg, raw)
-        with open(os.path.join(out, f"r5_pmc_{cfg}.txt"), "w") as f:
+        with open(os.path.join(out, f"{ROUND}_pmc_{cfg}.txt"), "w") as f:
             f.write(HEADER.format(what=TARGETS[cfg][2], head=head, traffic_mb=d["traffic_bytes"] / 1e6, algo_mb=d["algorithmic_bytes"] / 1e6, **d))
             for k in sorted(raw):
                 f.write(f"{k:32s} {raw[k][0]:.5e}   (n={raw[k][1]})\n")
-        allj[cfg] = dict(d, what=TARGETS[cfg][2], commit=head, file=f"profiles/r5_pmc_{cfg}.txt")
+        allj[cfg] = dict(d, what=TARGETS[cfg][2], commit=head, file=f"profiles/{ROUND}_pmc_{cfg}.txt")
         print(f"{cfg}: VALU-active {d['valu_active']:.1%}  MFMA-busy {d['mfma_busy']:.1%}  waves/SIMD {d['waves_per_simd']:.2f}  traffic {d['traffic_bytes'] / 1e6:.1f} MB "
               f"(x {d['traffic_over_algorithmic']:.2f})", flush=True)
         json.dump(allj, open(jpath, "w"), indent=1)

@@ -38,4 +38,12 @@ call5() {   # V rows, second take (operand addresses as immediates): bit-identit
   timeout 600 python tools/vrows_ab.py c2 c2nc c2l n2k 2>&1 | filter | tee $out/vrows_ab.txt
 }
 
+call6() {   # full suite at the commit + PMC passes per configuration + bench line
+  out=gpurun_out/r6f; mkdir -p $out
+  timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; filter < $out/pytest.log | tail -6
+  cp gpurun_out/parity_report.json $out/ 2>/dev/null
+  timeout 1500 python tools/pmc_collect.py r6f c3 c3f c2 c2r c2t c4 c4nc c5 c5f pp 2>&1 | filter | tee $out/pmc_summary.txt
+  timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -2 $out/bench.err; cut -c1-600 $out/bench.json
+}
+
 "$@"
