@@ -37,7 +37,7 @@ TARGETS = {   # cfg -> (command, kernel-name filter, what it is, algorithmic byt
     "c5": (["tools/run_kernel.py", "c5", "3"], "sage_attn_kernel", "C5 attention kernel (B2 H48 N17776 D64 non-causal, persistent launch, exact scores: the default)", 546.1e6),
     "c3f": (["tools/run_kernel.py", "c3", "3", "folded"], "sage_attn_kernel", "C3 attention kernel, the opt-in FOLDED score variant (fp8_scores=\"folded\")", 335.5e6),
     "c5f": (["tools/run_kernel.py", "c5", "3", "folded"], "sage_attn_kernel", "C5 attention kernel, the opt-in FOLDED score variant", 546.1e6),
-    "c2r": (["tools/run_kernel.py", "c2r", "3"], "sage_attn_kernel", "C2 default route on fp16 inputs: fused per-thread Q quantisation + V rows in place (fp16 q and v read: 2 B/elt each)", 335.5e6),
+    "c2r": (["tools/run_kernel.py", "c2r", "3"], "sage_attn_kernel", "C2 default route on fp16 inputs: fused per-thread Q quantisation + V rows in place (fp16 q and v read: 2 B/elt each)", 234.9e6),
     "pp": (["tools/run_prepass.py", "fused", "2,32,8192,128", "3"], "prepass_kv_kernel", "one-launch K / V pre-pass at the C3 shape (Infinity Cache flushed between launches)", 402.7e6),
 }
 
