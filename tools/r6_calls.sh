@@ -46,4 +46,10 @@ call6() {   # full suite at the commit + PMC passes per configuration + bench li
   timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -2 $out/bench.err; cut -c1-600 $out/bench.json
 }
 
+call7() {   # stress: the seeded sweeps with 400 seeds each (the suite draws 100), both FP8 score forms as the process default
+  out=gpurun_out/r6g; mkdir -p $out
+  SAGE_RANDOM_SEEDS=400 timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_prepass.py -m gpu -q -k "random" > $out/pytest_400.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_400.log; filter < $out/pytest_400.log | tail -6
+  SAGE_FP8_SCORES=folded SAGE_RANDOM_SEEDS=100 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_folded_default.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_folded_default.log; filter < $out/pytest_folded_default.log | tail -6
+}
+
 "$@"
