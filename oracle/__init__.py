@@ -139,24 +139,26 @@ def v_mean_padded16(v: np.ndarray, dtype: int) -> np.ndarray:
 
 
 def attn(q8, k8, v, q_scale, q_sidx, k_scale, k_sidx, *, causal: bool, c: float, pv_mode: int,
-         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False, mask_bool=None, mask_add=None, score_mode: int = SCORES_EXACT):
+         out_dtype: int, v_scale=None, v_mean=None, return_lse: bool = False, mask_bool=None, mask_add=None, score_mode: int = SCORES_EXACT,
+         tile_keys: int = 64):
     """Fused attention on quantised operands; returns (o bits uint16 [B,Hq,Lq,D], lse|None).  ``score_mode`` (FP8 modes): SCORES_EXACT
-    = the reference's formula, SCORES_FOLDED = the reassociation the gfx950 kernels' default FP8 loops evaluate (sage_oracle.c)."""
+    = the reference's formula, SCORES_FOLDED = the reassociation of the gfx950 kernels' opt-in folded variant (sage_oracle.c).
+    ``tile_keys``: keys per online-softmax iteration, 64 (sm80 / sm89 / Triton kernels, and every gfx950 kernel) or 128 (the sm90 kernel's CTA_K)."""
     B, Hq, Lq, D = q8.shape
     _, Hkv, Lk, _ = k8.shape
     o = np.empty((B, Hq, Lq, D), dtype=np.uint16)
     lse = np.empty((B, Hq, Lq), dtype=np.float32) if return_lse else None
     q_sidx = np.ascontiguousarray(q_sidx, dtype=np.int32)
     k_sidx = np.ascontiguousarray(k_sidx, dtype=np.int32)
-    rc = lib().orc_attn(_p(q8), _p(k8), _p(v), _p(o), _p(lse),
+    rc = lib().orc_attn_ex(_p(q8), _p(k8), _p(v), _p(o), _p(lse),
                         _p(q_scale), _p(q_sidx), int(q_scale.shape[-1]),
                         _p(k_scale), _p(k_sidx), int(k_scale.shape[-1]), _p(v_scale),
                         _p(None if v_mean is None else np.ascontiguousarray(v_mean, dtype=np.float32)),
                         _p(None if mask_bool is None else np.ascontiguousarray(np.broadcast_to(mask_bool, (B, Hq, Lq, Lk)), dtype=np.uint8)),
                         _p(None if mask_add is None else np.ascontiguousarray(np.broadcast_to(mask_add, (B, Hq, Lq, Lk)), dtype=np.float32)),
                         int(B), int(Hq), int(Hkv), int(Lq), int(Lk), int(D), int(causal),
-                        ctypes.c_float(float(c)), int(pv_mode), int(out_dtype), int(score_mode))
-    assert rc == 0, "orc_attn rejected the arguments"
+                        ctypes.c_float(float(c)), int(pv_mode), int(out_dtype), int(score_mode), int(tile_keys))
+    assert rc == 0, "orc_attn_ex rejected the arguments"
     return o, lse
 
 
@@ -183,7 +185,7 @@ def k_mean(k: np.ndarray, dtype: int) -> np.ndarray:
 
 def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smooth_k=True,
                    qk_quant_gran="per_block", pv="f16_triton", return_lse=False, km=None, warpq=32,
-                   smooth_v=False, vm=None, mask_bool=None, mask_add=None, blkk=64, fp8_scores="exact", single_level=False):
+                   smooth_v=False, vm=None, mask_bool=None, mask_add=None, blkk=64, fp8_scores="exact", single_level=False, tile_keys=64):
     """Whole-API restatement on HND arrays of fp16/bf16 bits.
 
     pv "f16_triton": sageattn_qk_int8_pv_fp16_triton (core.py:160-331), per-block quant with
@@ -191,7 +193,8 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
     pv "f8": sageattn_qk_int8_pv_fp8_cuda (core.py:636-826) with fp32+fp32 two-level
         accumulation; qk_quant_gran per_warp | per_thread (| per_block, our extension).
     pv "f16": sageattn_qk_int8_pv_fp16_cuda pv_accum_dtype="fp32" (core.py:451-633).
-    fp8_scores ("exact" | "folded", pv "f8" only): the form of the softmax argument, see ``attn`` (the product's default is "folded").
+    fp8_scores ("exact" | "folded", pv "f8" only): the form of the softmax argument, see ``attn`` (the product's default is "exact").
+    tile_keys (pv "f8"): 64, or 128 = the sm90 kernel's own iteration (qk_int_sv_f8_cuda_sm90.cu:285-356), see ``attn``.
     single_level (pv "f8"): pv_accum_dtype="fp32", every tile accumulated straight into the output.
     warpq / blkk: scale-group sizes of the CUDA-named APIs -- WARPQ 32, or 16 for head_dim 128 with
         "fp16+fp32" (core.py:602-604); the sm90 entry point uses WARPQ 16 and BLKK = WARPK = 128 (core.py:964-970).
@@ -241,7 +244,7 @@ def sageattn_dense(q, k, v, dtype: int, *, is_causal=False, sm_scale=None, smoot
         aux.update(v8=v8, vs=vs, vm=vm)
         o, lse = attn(q8, k8, v8, qs, gq, ks, gk, causal=is_causal, c=c, pv_mode=PV_F8_SINGLE if single_level else PV_F8_TWO_LEVEL,
                       out_dtype=dtype, v_scale=vs, v_mean=vm if smooth_v else None, return_lse=return_lse,
-                      score_mode={"exact": SCORES_EXACT, "folded": SCORES_FOLDED}[fp8_scores])
+                      score_mode={"exact": SCORES_EXACT, "folded": SCORES_FOLDED}[fp8_scores], tile_keys=tile_keys)
     else:
         mode = PV_F16_TRITON if pv == "f16_triton" else PV_F16_F32ACC
         if smooth_v:   # sub_mean (quant.py:182-222): vm = v.mean(seq) in the input dtype, (v - vm) -> fp16

@@ -304,18 +304,24 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  *   out-of-range keys load as False / -1e6 (`other=`), i.e. their score is exactly -1e6 (K loads as 0).
  */
 #define BM 128
-#define BN 64
+#define BN_MAX 128
 #define NEG_BIG (-1.0e30f)
 
-ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_t *o, float *lse,
-                        const float *q_scale, const int32_t *q_sidx, int nqs,
-                        const float *k_scale, const int32_t *k_sidx, int nks,
-                        const float *v_scale, const float *v_mean,
-                        const uint8_t *mask_b, const float *mask_f,
-                        int B, int Hq, int Hkv, int Lq, int Lk, int D,
-                        int causal, float c, int pv_mode, int out_dtype, int score_mode)
+/* tile_keys: keys per iteration of the online softmax -- one maximum update, one rescale and one two-level fold per tile.  64 = the sm80 / sm89
+ * kernels' CTA_K and the Triton kernels' BLOCK_N (and what the gfx950 kernels run for every entry point); 128 = the sm90 kernel's CTA_K
+ * (qk_int_sv_f8_cuda_sm90.cu:127-135,285-356: update_mdo over the 128 keys, RO_temp = P.V over them from zero, RO += RO_temp), with which
+ * every P of a tile's FIRST 64 keys is rounded against the maximum over all 128. */
+ORC_EXPORT int orc_attn_ex(const int8_t *q, const int8_t *k, const void *v, uint16_t *o, float *lse,
+                           const float *q_scale, const int32_t *q_sidx, int nqs,
+                           const float *k_scale, const int32_t *k_sidx, int nks,
+                           const float *v_scale, const float *v_mean,
+                           const uint8_t *mask_b, const float *mask_f,
+                           int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                           int causal, float c, int pv_mode, int out_dtype, int score_mode, int tile_keys)
 {
     if (D > 128 || Hq % Hkv) return -1;
+    if (tile_keys != 64 && (tile_keys != 128 || mask_b || mask_f)) return -1;
+    const int BN = tile_keys;
     if (score_mode != 0 && (score_mode != 1 || pv_mode < 2 || mask_b || mask_f)) return -1;
     const float bias = bits_f(0x3E22F983u);          /* 1 / (2 pi) as the kernels' MFMA C operand */
     const int g = Hq / Hkv;
@@ -342,7 +348,7 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                 const int r0 = qb * BM, rows = (Lq - r0 < BM) ? Lq - r0 : BM;
                 float m[BM], l[BM];
                 float (*acc)[128] = malloc(sizeof(float) * BM * 128);
-                float (*p)[BN] = malloc(sizeof(float) * BM * BN);
+                float (*p)[BN_MAX] = malloc(sizeof(float) * BM * BN_MAX);
                 float tile[128];
                 for (int i = 0; i < BM; i++) { m[i] = NEG_BIG; l[i] = 0.0f; }
                 memset(acc, 0, sizeof(float) * BM * 128);
@@ -364,8 +370,8 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
                         const int8_t *qr = qp + (size_t)(r0 + i) * D;
                         const float qsc = qs[q_sidx[r0 + i]];
                         float mx = NEG_BIG;       /* non-fused: max score; fused: max of (score - offset) */
-                        float dotf[BN], ccj[BN];
-                        int32_t doti[BN];
+                        float dotf[BN_MAX], ccj[BN_MAX];
+                        int32_t doti[BN_MAX];
                         /* pv_mode 0 restates the Triton kernel literally: qk = dot * (q_scale*k_scale), then
                          * qk - m (attn_qk_int8_per_block.py:41,53-55).  The other modes restate the CUDA kernels:
                          *   dequant_scale = q_scale * k_scale;  sm_scale' = (sm_scale*log2e) * dequant_scale
@@ -460,4 +466,16 @@ ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_
     return 0;
 }
 
-ORC_EXPORT int orc_version(void) { return 2; }
+ORC_EXPORT int orc_attn(const int8_t *q, const int8_t *k, const void *v, uint16_t *o, float *lse,
+                        const float *q_scale, const int32_t *q_sidx, int nqs,
+                        const float *k_scale, const int32_t *k_sidx, int nks,
+                        const float *v_scale, const float *v_mean,
+                        const uint8_t *mask_b, const float *mask_f,
+                        int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                        int causal, float c, int pv_mode, int out_dtype, int score_mode)
+{
+    return orc_attn_ex(q, k, v, o, lse, q_scale, q_sidx, nqs, k_scale, k_sidx, nks, v_scale, v_mean, mask_b, mask_f, B, Hq, Hkv, Lq, Lk, D,
+                       causal, c, pv_mode, out_dtype, score_mode, 64);
+}
+
+ORC_EXPORT int orc_version(void) { return 3; }

@@ -348,6 +348,15 @@ def test_sm90_entry_point_scale_groups_vs_oracle(oracle_mod, case, causal, gran)
     REPORT[f"sm90_groups/{name}/{'c' if causal else 'nc'}/{gran}"] = dict(max_abs=err, max_o=scale)
     assert np.isfinite(got).all() and err <= 2e-3 * scale + (2 ** -7 if dt == 1 else 2 ** -10) * scale
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 5e-3
+    # the reference's OWN sm90 kernel iterates over 128 keys (one maximum update and one RO += RO_temp per 128 keys, sm90.cu:285-356); ours takes
+    # 64, like the oracle above.  Against the oracle in the 128-key schedule the distance is that of re-rolled e4m3 roundings: a statistical bar
+    # (tests/test_oracle_golden.py::test_sm90_tile_schedule_64_vs_128_keys pins the two oracle schedules against each other at the same bar)
+    o128, _, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f8", qk_quant_gran=gran, km=km,
+                                           warpq=16, blkk=128, fp8_scores=SCORES, tile_keys=128)
+    r128 = util.f32(o128, dt)
+    rel_rms = float(np.sqrt(((got - r128) ** 2).mean() / (r128 ** 2).mean()))
+    REPORT[f"sm90_groups/{name}/{'c' if causal else 'nc'}/{gran}"].update(rel_rms_vs_128_key_schedule=rel_rms, max_abs_vs_128=float(np.abs(got - r128).max()))
+    assert rel_rms <= 1.5e-2 and np.abs(got - r128).max() <= 3e-2 * scale
     # the INT8 operands themselves: bit-exact against the oracle's quantiser with the same groups
     q8, qs, k8, ks = (sq.per_warp_int8(q.to(DEV), k.to(DEV), util.from_bits(km, dt, DEV), BLKQ=128, WARPQ=16, BLKK=128) if gran == "per_warp"
                       else sq.per_thread_int8(q.to(DEV), k.to(DEV), util.from_bits(km, dt, DEV), BLKQ=128, WARPQ=16, BLKK=128, WARPK=128))
@@ -425,7 +434,7 @@ def test_degenerate_inputs_vs_oracle(oracle_mod, api, what):
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     km = util.bits(sq.channel_mean(kd))
     fp8 = api.startswith("f8")
-    form = "folded" if api == "f8f" else "exact"
+    form = "folded" if api == "f8f" else ("exact" if api != "f8" else SCORES)      # (SAGE_FP8_SCORES=folded runs of the suite: the process default's own oracle mode)
     for causal in (False, True):
         if api == "triton":
             ref, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=causal, pv="f16_triton",
