@@ -287,8 +287,8 @@ ORC_EXPORT int orc_quant_v_fp8(const uint16_t *v, int dtype, uint8_t *out, float
  * out dtype: 0 fp16, 1 bf16.
  * score_mode (FP8 modes 2 / 3 only; 0 everywhere else):
  *   0 "exact":  P = exp2(fma(raw score, sm_scale', -m)), the reference's formula (attn_utils.cuh:445-449) -- the mode that is pinned to
- *               the reference text and that the gfx950 kernels run under SAGE_ATTR_FP8_EXACT_SCORES.
- *   1 "folded": the SAME formula reassociated as the gfx950 kernels' default FP8 loops evaluate it.  They read the INT32 accumulator,
+ *               the reference text and that every gfx950 kernel runs by default (since round 6).
+ *   1 "folded": the SAME formula reassociated as the gfx950 kernels' OPT-IN FP8 variant (SAGE_ATTR_FP8_FOLDED_SCORES) evaluates it.  It reads the INT32 accumulator,
  *               which starts from the bit pattern 0x3E22F983 (the float 1/(2 pi)), as the float  x = bias + s * 2^-26  (exact for
  *               |s| <= 2^21) and form, with c' = sm_scale' * 2^26 (a power-of-two scaling: exact),
  *                   mb = fma(bias, c', m)          rounded ONCE per (row, 64-key tile, k scale)

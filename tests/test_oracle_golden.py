@@ -141,9 +141,9 @@ def test_two_level_equals_single_level_to_rounding(oracle_mod):
                          ids=["n300_d128_causal", "n512_d64", "n1000_d128_biased_k_bf16", "cross_d64_per_warp", "long_kv_per_block"])
 def test_folded_scores_vs_exact(oracle_mod, case):
     """The oracle's two FP8 score forms on the CPU.  `exact` is the reference's formula exp2(fma(s, c, -m)) (attn_utils.cuh:445-449) and
-    stays the pinned mode; `folded` is its reassociation exp2(fma(bits, c', -(m + bias c'))) as the gfx950 kernels' default FP8 loops
-    evaluate it.  Clause (ii) of the rule for a default FP8 schedule variant: rel-RMS <= 1e-2 between the two; clause
-    (iii): accuracy against fp32 SDPA within 1e-4 (cos) / 1e-3 (rel-RMSE) of the exact form's.  The forms are NOT equal: single outputs of
+    stays the pinned mode; `folded` is its reassociation exp2(fma(bits, c', -(m + bias c'))) as the gfx950 kernels' opt-in FP8 variant
+    evaluates it.  What the variant is held to besides its own oracle mode: rel-RMS <= 1e-2 between the two forms on ordinary
+    inputs, and accuracy against fp32 SDPA within 1e-4 (cos) / 1e-3 (rel-RMSE) of the exact form's.  The forms are NOT equal: single outputs of
     rows of a few hundred keys differ by up to ~1.5e-2 * max|o| (an e4m3 rounding of a large P flips), which is why each form has its own
     2e-3 gate instead of one gate for both."""
     B, Hq, Hkv, Lq, Lk, D, dt, causal, kbias, gran = case
