@@ -63,6 +63,16 @@
 #define SAGE_SCALE2_EXACT(d0, d1, s0, s1, c0, c1, m) "v_add_f32 " d0 ", 0xbe22f983, " s0 "\n\tv_add_f32 " d1 ", 0xbe22f983, " s1 "\n\t" \
                                                       "v_fma_f32 " d0 ", " d0 ", " c0 ", -" m "\n\tv_fma_f32 " d1 ", " d1 ", " c1 ", -" m "\n\t"
 
+// The pipelined loops' rename of the score tiles, set B -> set A (sA, sB: v16i[2] in scope), behind a body whose last instructions are the
+// asm-issued MFMAs that write sB.  Plain copies (sA = sB) are moves the compiler is free to place right behind that asm -- inside the MFMAs'
+// latency, which it does not see (round 5's wrong rows; an in-out nop statement in front of the copies does not help: the allocator may
+// satisfy its tie by copying first).  So the copy is issued from asm as well, on the matrix pipe: D = 0 * 0 + C moves sixteen registers per
+// instruction, exactly (INT32), behind the wait states an MFMA reading another MFMA's result as SrcC needs, and followed by those a VALU
+// reader of its own result needs (tools/mfma_hazard_lint.py checks both).
+#define SAGE_RENAME_S() do { const v4i z4_ = {0, 0, 0, 0};                                                                   \
+        asm volatile("s_nop 15\n\ts_nop 7\n\tv_mfma_i32_32x32x32_i8 %0, %2, %2, %3\n\tv_mfma_i32_32x32x32_i8 %1, %2, %2, %4\n\t"     \
+                     "s_nop 15\n\ts_nop 7" : "=&v"(sA[0]), "=&v"(sA[1]) : "v"(z4_), "v"(sB[0]), "v"(sB[1])); } while (0)
+
 namespace sage {
 
 // hwreg(HW_REG_MODE, 23, 1): the FP16_OVFL bit of the MODE register (id 1 | offset 23 << 6 | (width 1 - 1) << 11)
@@ -864,6 +874,7 @@ sage_attn_kernel(const AttnParams p_arg)
     int it = 0;
     if constexpr (MASK == 0) {
         static_assert(NH == 1 && NSTAGE == 3, "the pipelined loops are written for 64-key iterations on the 3-slot ring");
+        constexpr bool SIX_BODIES = D == 128;          // the pipelined loops' ring slot as a compile-time constant (see the FP8 loop)
         // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
@@ -938,11 +949,14 @@ sage_attn_kernel(const AttnParams p_arg)
                     }
                 };
                 // one tile: sc = scores of tile `it` (complete), sn <- scores of tile it+1, pp = P of tile it-1, pc <- P of tile it
-                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {
+                // (`slot` = the ring slot of tile `it`, a compile-time constant: the six bodies of the loop below are the six combinations of
+                //  ring slot and score-register set, so every LDS address of a body is a loop-invariant per-lane offset plus an immediate --
+                //  no per-tile address arithmetic on the VALU)
+                auto body = [&](auto slot, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {
                     rescale();
-                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-                    const unsigned char *vs = smem + cur * C::STAGE_BYTES + C::K_TILE_BYTES;
+                    const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
+                    const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                    const unsigned char *vs = smem + CUR * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -1008,7 +1022,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     A_FENCE();
 
                     // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
-                    float rs0 = 0.0f, rs1 = 0.0f;
+                    float rs0, rs1;                  // partial row sums: defined by the first group (grp(0) / g4b(0))
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
@@ -1020,18 +1034,28 @@ sage_attn_kernel(const AttnParams p_arg)
                                      "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\t" PACK                                      \
                                      : "+v"(rs0), "+v"(rs1), "=&v"(t0), "=&v"(t1), "+v"(pc[h >> 1])                               \
                                      : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"((KTHREAD && (i0 & 2)) ? mb1 : mb0))
+                        // (the first group DEFINES the two partial row sums -- 0 + p is p: no zero initialisation, no add)
+#define SAGE_GRP0(SCALE2)                                                                                                       \
+                        asm volatile(SCALE2("%0", "%1", "%3", "%4", "%5", "%6", "%7")                                             \
+                                     "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_cvt_pk_fp8_f32 %2, %0, %1"                \
+                                     : "=&v"(rs0), "=&v"(rs1), "+v"(pc[0])                                                        \
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"((KTHREAD && (i0 & 2)) ? mb1 : mb0))
                         if constexpr (SFOLD) {
-                            if ((h & 1) == 0) SAGE_GRP(SAGE_SCALE2_FOLD, "v_cvt_pk_fp8_f32 %4, %2, %3");
+                            if (h == 0) SAGE_GRP0(SAGE_SCALE2_FOLD);
+                            else if ((h & 1) == 0) SAGE_GRP(SAGE_SCALE2_FOLD, "v_cvt_pk_fp8_f32 %4, %2, %3");
                             else SAGE_GRP(SAGE_SCALE2_FOLD, "v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
                         } else {
-                            if ((h & 1) == 0) SAGE_GRP(SAGE_SCALE2_EXACT, "v_cvt_pk_fp8_f32 %4, %2, %3");
+                            if (h == 0) SAGE_GRP0(SAGE_SCALE2_EXACT);
+                            else if ((h & 1) == 0) SAGE_GRP(SAGE_SCALE2_EXACT, "v_cvt_pk_fp8_f32 %4, %2, %3");
                             else SAGE_GRP(SAGE_SCALE2_EXACT, "v_cvt_pk_fp8_f32 %4, %2, %3 op_sel:[0,0,1]");
                         }
+#undef SAGE_GRP0
 #undef SAGE_GRP
                     };
+                    auto &qfr = qf;                  // (named in the generic body itself: a lambda nested in it does not capture through it otherwise)
                     auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
-                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
+                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
+                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
                     };
                     auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
                         const int drow = dt * 32 + n;
@@ -1059,6 +1083,12 @@ sage_attn_kernel(const AttnParams p_arg)
 #undef SAGE_G4A
                     };
                     auto g4b = [&](int w) {
+                        if (w == 0)                  // (defines the partial row sums: 0 + u0 + u2 is u0 + u2)
+                            asm volatile("v_add_f32 %0, %3, %5\n\tv_add_f32 %1, %4, %6\n\t"
+                                         "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
+                                         : "=&v"(rs0), "=&v"(rs1), "+v"(pc[w])
+                                         : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+                        else
                         asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
                                      "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
                                      : "+v"(rs0), "+v"(rs1), "+v"(pc[w])
@@ -1094,21 +1124,40 @@ sage_attn_kernel(const AttnParams p_arg)
                     l_run = l_run * alpha + (rs0 + rs1);
                     cs[0] = sm26 * (qsc * ksc_next[0][0]);
                     cs[1] = KTHREAD ? sm26 * (qsc * ksc_next[0][1]) : cs[0];
-                    cur = nxt;
                     alpha_p = alpha;
                     it++;
                 };
-                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
-                    body(sA, sB, pA, pB);
-                    // the nops carry the renamed registers as operands: the copies below are plain moves, which the compiler
-                    // otherwise schedules above the nops, i.e. into the latency of the MFMAs (inside the asm of body) that write sB
-                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sB[0]), "+v"(sB[1])::"memory");
-                    sA[0] = sB[0]; sA[1] = sB[1]; pA = pB;
-                }
+                // The loop enters with tile `it` in slot 0 (cur == 0: no general iteration runs in front of it) and its scores in set A.  Six bodies --
+                // the six combinations of ring slot and register set, the slot a compile-time constant in each -- bring both back to where they
+                // were; what is left of the count (< 6) runs one body at a time on a run-time slot, renamed B -> A behind it (a few times per workgroup).
+                // (D = 64 has no registers to spare under its three-waves limit for the six bodies' loop-invariant addresses: its loop is the
+                //  remainder loop's body twice, on run-time slots)
+                {
+                    const int left = n_steady - it;
+                    int n6 = SIX_BODIES ? left / 6 : 0, r = left - 6 * n6;
+                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                    if constexpr (SIX_BODIES) {
 #pragma nounroll
-                while (it < n_steady) {
-                    body(sA, sB, pA, pB);
-                    body(sB, sA, pB, pA);
+                        for (; n6 > 0; n6--) {
+                            body(I0{}, sA, sB, pA, pB); body(I1{}, sB, sA, pB, pA); body(I2{}, sA, sB, pA, pB);
+                            body(I0{}, sB, sA, pB, pA); body(I1{}, sA, sB, pA, pB); body(I2{}, sB, sA, pB, pA);
+                        }
+                    }
+#define SAGE_REST() do { body(cur, sA, sB, pA, pB); SAGE_RENAME_S(); pA = pB; cur = (cur + 1 == NSTAGE) ? 0 : cur + 1; } while (0)
+                    if constexpr (SIX_BODIES) {
+#pragma nounroll
+                        for (; r > 0; r--) SAGE_REST();
+                    } else {
+                        if (r & 1) SAGE_REST();           // odd count: one tile first, renamed (once per workgroup)
+#pragma nounroll
+                        while (it < n_steady) {
+                            body(cur, sA, sB, pA, pB);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            body(cur, sB, sA, pB, pA);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+                    }
+#undef SAGE_REST
                 }
                 // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
                 // iteration issues the LDS-DMA of tile it+2 into that slot
@@ -1184,16 +1233,18 @@ sage_attn_kernel(const AttnParams p_arg)
                             for (int i = 0; i < 16; i++) o[dt][i] *= alpha_p;
                     }
                 };
-                bool first = true;                 // no previous tile yet: P = 0 against the (finite) V of the current slot
                 // CUDA kernel form (TWO_LEVEL false): row sum of the fp16-rounded P; Triton kernel form (TWO_LEVEL true): of the
                 // un-rounded P (see tile_iter)
                 constexpr bool RSUM16 = !TWO_LEVEL;
-                auto body = [&](v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
+                // (`slot` = the ring slot of tile `it`, a compile-time constant as in the FP8 loop: every LDS address of a body is a loop-invariant
+                //  per-lane offset plus an immediate.  `first`: the work item's first body has no previous tile -- P = 0 against the (finite) V
+                //  of the current slot instead of slot (cur + 2) % 3, which nothing has been written to yet)
+                auto body = [&](auto slot, auto first, v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
                     rescale();
-                    const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                    const int nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-                    const int prv = first ? cur : nn;                 // slot of tile t-1 = (cur + 2) % 3
-                    first = false;
+                    const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
+                    const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+                    const bool FIRST = first;        // (std::true_type / false_type in the D = 128 loops; a bool in the D = 64 loop)
+                    const int prv = FIRST ? CUR : nn;                                      // slot of tile t-1 = (cur + 2) % 3
                     const unsigned char *vsp = smem + prv * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1277,14 +1328,29 @@ sage_attn_kernel(const AttnParams p_arg)
                     if constexpr (C::DT > 1) read_v(1, vfb);
                     A_FENCE();
 
-                    float rs0 = 0.0f, rs1 = 0.0f;
+                    float rs0, rs1;                  // partial row sums: defined by grp(0)
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32: bias sub, scale fma, exp2, fp16 pack, row sum
                         const int c = h >> 2, j0 = (h & 3) * 2;
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
                         const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
                         const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
-                        if constexpr (RSUM16) {
+                        if (h == 0) {
+                            // the first group DEFINES the two partial row sums (0 + p is p: no zero initialisation; the un-rounded form needs no add)
+                            if constexpr (RSUM16)
+                                asm volatile(SAGE_SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")
+                                             "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+                                             "s_nop 0\n\tv_cvt_pk_f16_f32 %4, %2, %3\n\t"
+                                             "v_fma_mix_f32 %0, %4, 1.0, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                                             "v_fma_mix_f32 %1, %4, 1.0, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                             : "=&v"(rs0), "=&v"(rs1), "=&v"(t0), "=&v"(t1), "=&v"(pc[c][h & 3])
+                                             : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
+                            else
+                                asm volatile(SAGE_SCALE2("%0", "%1", "%3", "%4", "%5", "%6", "%7")
+                                             "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\ts_nop 0\n\tv_cvt_pk_f16_f32 %2, %0, %1"
+                                             : "=&v"(rs0), "=&v"(rs1), "=&v"(pc[c][h & 3])
+                                             : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(ca), "v"(cb), "v"(mb));
+                        } else if constexpr (RSUM16) {
                             // row sum of the ROUNDED pair in FP32: v_fma_mix_f32 reads a half of the packed word as its f16 operand
                             // (rs += f32(half) * 1.0).  Not v_dot2_f32_f16: the dot instructions flush fp16 subnormals whatever the
                             // mode, and a long row's many probabilities below 2^-14 are a visible share of its denominator (seen as
@@ -1313,12 +1379,14 @@ sage_attn_kernel(const AttnParams p_arg)
                         for (int kk = 0; kk < C::KSTEPS; kk++)
                             kf[kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
                     };
+                    auto &o_r = o;                   // (named in the generic body itself, as qfr below)
                     auto pv4 = [&](int dt, v4i (&vf)[4], int c) {
-                        A_PV16(o[dt], vf[c], pp[c]);
+                        A_PV16(o_r[dt], vf[c], pp[c]);
                     };
+                    auto &qfr = qf;                  // (named in the generic body itself: a lambda nested in it does not capture through it otherwise)
                     auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qf[0]);
-                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qf[kk]);
+                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
+                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
                     };
                     if constexpr (C::DT == 4) {
                         // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
@@ -1371,24 +1439,52 @@ sage_attn_kernel(const AttnParams p_arg)
                     l_run = l_run * alpha + (rs0 + rs1);
                     ksc[0][0] = ksc_next[0][0];
                     ksc[0][1] = ksc_next[0][1];
-                    cur = nxt;
                     alpha_p = alpha;
                     moved_p = moved;
                     it++;
                 };
-                if ((n_steady - it) & 1) {           // odd count: one tile, then rename B -> A (once per workgroup)
-                    body(sA, sB, pA, pB);
-                    // the nops carry the renamed registers as operands: the copies below are plain moves, which the compiler
-                    // otherwise schedules above the nops, i.e. into the latency of the MFMAs (inside the asm of body) that write sB
-                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sB[0]), "+v"(sB[1])::"memory");
-                    sA[0] = sB[0]; sA[1] = sB[1];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pA[c] = pB[c];
-                }
+                // The loop enters with tile `it` in slot 0 (cur == 0) and its scores in set A.  The first body is peeled (it alone has no previous
+                // tile) and renamed B -> A; six bodies -- the six combinations of ring slot and register set from slot 1 on, the slot a compile-time
+                // constant in each -- bring both back to where they were; what is left of the count (< 6) runs one body at a time on a run-time
+                // slot, renamed behind it (a few times per workgroup).
+                {
+#define SAGE_RENAME() do { SAGE_RENAME_S(); _Pragma("unroll") for (int c = 0; c < 4; c++) pA[c] = pB[c]; } while (0)
+                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                    if constexpr (SIX_BODIES) {
+                        const int left = n_steady - it - 1;
+                        body(I0{}, std::true_type{}, sA, sB, pA, pB);
+                        SAGE_RENAME();
+                        cur = 1;
+                        int n6 = left / 6, r = left - 6 * n6;
 #pragma nounroll
-                while (it < n_steady) {
-                    body(sA, sB, pA, pB);
-                    body(sB, sA, pB, pA);
+                        for (; n6 > 0; n6--) {
+                            body(I1{}, std::false_type{}, sA, sB, pA, pB); body(I2{}, std::false_type{}, sB, sA, pB, pA); body(I0{}, std::false_type{}, sA, sB, pA, pB);
+                            body(I1{}, std::false_type{}, sB, sA, pB, pA); body(I2{}, std::false_type{}, sA, sB, pA, pB); body(I0{}, std::false_type{}, sB, sA, pB, pA);
+                        }
+#pragma nounroll
+                        for (; r > 0; r--) {
+                            body(cur, std::false_type{}, sA, sB, pA, pB);
+                            SAGE_RENAME();
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+                    } else {            // (D = 64: see the FP8 loop)
+                        bool first_rt = true;
+                        if ((n_steady - it) & 1) {           // odd count: one tile first, renamed (once per workgroup)
+                            body(cur, first_rt, sA, sB, pA, pB);
+                            first_rt = false;
+                            SAGE_RENAME();
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+#pragma nounroll
+                        while (it < n_steady) {
+                            body(cur, first_rt, sA, sB, pA, pB);
+                            first_rt = false;
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            body(cur, std::false_type{}, sB, sA, pB, pA);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+                    }
+#undef SAGE_RENAME
                 }
                 // drain: PV of the last pipelined tile (its V is in slot (cur + 2) % 3); V(it+1) is requested so that the general
                 // iteration finds tile it+1 "in flight" as a whole; then tile `it` must be complete and every wave past its reads

@@ -52,4 +52,10 @@ call7() {   # stress: the seeded sweeps with 400 seeds each (the suite draws 100
   SAGE_FP8_SCORES=folded SAGE_RANDOM_SEEDS=100 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_folded_default.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_folded_default.log; filter < $out/pytest_folded_default.log | tail -6
 }
 
+call9() {   # loop trimming (row-sum definition by the first group; compile-time ring slots at D = 128; rename on the matrix pipe): bit-identity A/B against the library before it, then the parity suite
+  out=gpurun_out/r6i; mkdir -p $out
+  for t in c3 c5 c2 c2t c4 c4nc n2k n32k; do timeout 300 python tools/lib_ab.py $t base main 2>&1 | filter | tee -a $out/trim_ab.txt; done
+  timeout 1700 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $out/pytest_parity.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_parity.log; filter < $out/pytest_parity.log | tail -6
+}
+
 "$@"
