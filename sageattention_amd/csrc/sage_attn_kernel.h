@@ -95,11 +95,12 @@ template <int D, bool PV_FP8, int NH> struct TileCfg {
 // c/d register r of a 32x32 MFMA tile -> row index inside the tile (lane half g = lane>>5)
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-// raw QK^T accumulator -> float score (in units of kSUnit^-1).
+// raw QK^T accumulator -> float score (in units of 2^-kSUnitLog2).
 // 0x3E22F983 lies mid-binade ([0.125, 0.25), ulp 2^-26, mantissa field 2292099): for |s| <= 128 * 128 * 128 = 2097152 the sum
 // stays inside the binade, so bits + s is the float 1/(2 pi) + s * 2^-26, the subtraction below is exact (Sterbenz) and
 // fma(s * 2^-26, c * 2^26, -m) rounds the same real number as fma((float)s, c, -m): bit-identical to the conversion.
-constexpr float kSUnit = 67108864.0f;       // 2^26: folded into the score scale
+constexpr int kSUnitLog2 = 26;              // 2^26 is folded into the score scale -- by v_ldexp_f32 (exact, as a multiplication by 2^26 is, and the
+                                            // exponent is an inline operand: the constant 2^26 in a VGPR was one the D = 64 instantiations spilled)
 __device__ __forceinline__ float sfl(int x) { return __int_as_float(x) - __int_as_float(0x3E22F983); }
 // first MFMA of a QK^T accumulation chain: C = kSInit as an inline constant (hipcc materialises an integer splat of
 // 0x3E22F983 in 16 VGPRs instead; the assembler encodes it as inline operand 248).  The builtin MFMAs that follow take the
@@ -347,11 +348,12 @@ sage_attn_kernel(const AttnParams p_arg)
 
     SAGE_TSTAMP(1);
     const int row0 = qblk * BLKQ + wave * 32;        // first query row of this wave
-    const int my_row = row0 + n;
+    int my_row = row0 + n;                           // (re-derived behind the pipelined loops, see there)
     // causal mask in the chunk's key coordinates (split-KV: this workgroup sees keys kchunk0 .. kchunk0 + Lk - 1 as 0 .. Lk - 1):
     // key <= row  <=>  local key <= row - kchunk0
     const int kchunk0 = (CAUSAL && p.kv_split > 1 && p.cu_q == nullptr) ? (hk % p.kv_split) * Lk : 0;
-    const int crow0 = row0 - kchunk0, cmy_row = my_row - kchunk0;
+    const int crow0 = row0 - kchunk0;
+    int cmy_row = my_row - kchunk0;
     const int ntk_all = (Lk + BLKK - 1) / BLKK;      // 64-key images that exist
     int n_iters = (Lk + KT - 1) / KT;
     if (CAUSAL) {
@@ -423,6 +425,7 @@ sage_attn_kernel(const AttnParams p_arg)
             return *reinterpret_cast<const v4i *>(vs + drow * 128 + swz_chunk<128>(drow, 4 * g + c) * 16);
         }
     };
+    int lane_g = lane;                      // the lane index as the ragged tile loads see it (laundered behind the pipelined loops, see there)
     auto issue_loads = [&](int it, int buf) {
         unsigned char *ks = smem + buf * C::STAGE_BYTES;
         unsigned char *vs = ks + C::K_TILE_BYTES;
@@ -438,7 +441,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
             for (int i = 0; i < KP / 4; i++) {
                 const int pc = wave * (KP / 4) + i;
-                const int e = pc * 64 + lane;
+                const int e = pc * 64 + lane_g;
                 const int row = e / CPR, phys = e % CPR;
                 int key = it * KT + row;
                 key = key < Lk ? key : Lk - 1;
@@ -673,8 +676,8 @@ sage_attn_kernel(const AttnParams p_arg)
             float cs[NH][2];
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) {
-                cs[hh][0] = (p.sm_scale_log2 * (qsc * ksc[hh][0])) * kSUnit;
-                cs[hh][1] = KTHREAD ? (p.sm_scale_log2 * (qsc * ksc[hh][1])) * kSUnit : cs[hh][0];
+                cs[hh][0] = __builtin_ldexpf(p.sm_scale_log2 * (qsc * ksc[hh][0]), kSUnitLog2);
+                cs[hh][1] = KTHREAD ? __builtin_ldexpf(p.sm_scale_log2 * (qsc * ksc[hh][1]), kSUnitLog2) : cs[hh][0];
             }
 
             // ---- online softmax over the iteration's keys ----
@@ -803,10 +806,10 @@ sage_attn_kernel(const AttnParams p_arg)
                                 const unsigned char *vr = vs + hh * C::V_IMG_BYTES + drow * 64;
                                 const v4u va = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g) * 16);
                                 const v4u vb = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
-                                // one K=64 block-scaled MFMA (fp8 x fp8, E8M0 scales = 127 -> x1.0)
+                                // one K = 64 FP8 MFMA (the plain form: no block scales)
                                 const v8i av = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};
                                 const v8i bv = {pw[hh][0], pw[hh][1], pw[hh][2], pw[hh][3], pw[hh][4], pw[hh][5], pw[hh][6], pw[hh][7]};
-                                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0, 0, 0);    // (zero scale operands: hipcc selects the plain v_mfma_f32_32x32x64_f8f6f4, no scale VGPRs)
                             }
                         }
                         if (FOLD) {
@@ -874,7 +877,7 @@ sage_attn_kernel(const AttnParams p_arg)
     int it = 0;
     if constexpr (MASK == 0) {
         static_assert(NH == 1 && NSTAGE == 3, "the pipelined loops are written for 64-key iterations on the 3-slot ring");
-        constexpr bool SIX_BODIES = D == 128;          // the pipelined loops' ring slot as a compile-time constant (see the FP8 loop)
+        constexpr bool SIX_BODIES = D == 128 || PV_FP8;         // the pipelined loops' ring slot as a compile-time constant (see the FP8 loop; not D = 64 FP16 PV)
         // whole tiles: it < Lk/64; unmasked for wave 0 (hence all waves): 64 it + 63 <= 128 qblk; two whole tiles follow
         int n_steady = Lk / KT - 2;
         n_steady = n_steady < n_iters - 2 ? n_steady : n_iters - 2;
@@ -932,7 +935,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
                 const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;    // piece 1's source offset minus its inst_offset
-                const float sm26 = p.sm_scale_log2 * kSUnit;
+                const float sm26 = __builtin_ldexpf(p.sm_scale_log2, kSUnitLog2);
                 // the tile's score scales (sm * (q_scale * k_scale)) * 2^26 == (sm * 2^26) * (q_scale * k_scale): exact power-of-two scaling.
                 // Carried from iteration to iteration in place of the k scales they are formed from (per-thread k scales are per-lane values:
                 // two VGPRs less across the loop; the general iterations behind the loop fetch their k scales again)
@@ -952,7 +955,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 // (`slot` = the ring slot of tile `it`, a compile-time constant: the six bodies of the loop below are the six combinations of
                 //  ring slot and score-register set, so every LDS address of a body is a loop-invariant per-lane offset plus an immediate --
                 //  no per-tile address arithmetic on the VALU)
-                auto body = [&](auto slot, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {
+                auto body = [&](auto slot, const int n, const int g, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {   // (n, g: the lane's row and half, see the remainder loop)
                     rescale();
                     const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
                     const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
@@ -1130,34 +1133,28 @@ sage_attn_kernel(const AttnParams p_arg)
                 // The loop enters with tile `it` in slot 0 (cur == 0: no general iteration runs in front of it) and its scores in set A.  Six bodies --
                 // the six combinations of ring slot and register set, the slot a compile-time constant in each -- bring both back to where they
                 // were; what is left of the count (< 6) runs one body at a time on a run-time slot, renamed B -> A behind it (a few times per workgroup).
-                // (D = 64 has no registers to spare under its three-waves limit for the six bodies' loop-invariant addresses: its loop is the
-                //  remainder loop's body twice, on run-time slots)
                 {
+                    static_assert(SIX_BODIES, "FP8 PV: both head sizes run the six-body loop");
                     const int left = n_steady - it;
-                    int n6 = SIX_BODIES ? left / 6 : 0, r = left - 6 * n6;
+                    int n6 = left / 6, r = left - 6 * n6;
                     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-                    if constexpr (SIX_BODIES) {
 #pragma nounroll
-                        for (; n6 > 0; n6--) {
-                            body(I0{}, sA, sB, pA, pB); body(I1{}, sB, sA, pB, pA); body(I2{}, sA, sB, pA, pB);
-                            body(I0{}, sB, sA, pB, pA); body(I1{}, sA, sB, pA, pB); body(I2{}, sB, sA, pB, pA);
-                        }
+                    for (; n6 > 0; n6--) {
+                        body(I0{}, n, g, sA, sB, pA, pB); body(I1{}, n, g, sB, sA, pB, pA); body(I2{}, n, g, sA, sB, pA, pB);
+                        body(I0{}, n, g, sB, sA, pB, pA); body(I1{}, n, g, sA, sB, pA, pB); body(I2{}, n, g, sB, sA, pB, pA);
                     }
-#define SAGE_REST() do { body(cur, sA, sB, pA, pB); SAGE_RENAME_S(); pA = pB; cur = (cur + 1 == NSTAGE) ? 0 : cur + 1; } while (0)
-                    if constexpr (SIX_BODIES) {
+                    // (the remainder body's per-lane LDS offsets are derived behind the six-body loop from a lane index the compiler cannot see
+                    //  through: formed in front of it they would stay live across it, next to that loop's own -- registers D = 64 does not have)
+                    int lane_r = lane;
+                    asm volatile("" : "+v"(lane_r));
+                    const int n_r = lane_r & 31, g_r = lane_r >> 5;
 #pragma nounroll
-                        for (; r > 0; r--) SAGE_REST();
-                    } else {
-                        if (r & 1) SAGE_REST();           // odd count: one tile first, renamed (once per workgroup)
-#pragma nounroll
-                        while (it < n_steady) {
-                            body(cur, sA, sB, pA, pB);
-                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                            body(cur, sB, sA, pB, pA);
-                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                        }
+                    for (; r > 0; r--) {
+                        body(cur, n_r, g_r, sA, sB, pA, pB);
+                        SAGE_RENAME_S();
+                        pA = pB;
+                        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                     }
-#undef SAGE_REST
                 }
                 // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
                 // iteration issues the LDS-DMA of tile it+2 into that slot
@@ -1216,7 +1213,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 v4i pA[4], pB[4];                  // P of a tile as fp16 pairs: [chunk of 16 keys][word] = B operands of the PV MFMAs
 #pragma unroll
                 for (int c = 0; c < 4; c++) { pA[c] = v4i{0, 0, 0, 0}; pB[c] = v4i{0, 0, 0, 0}; }
-                const float sm26 = p.sm_scale_log2 * kSUnit;
+                const float sm26 = __builtin_ldexpf(p.sm_scale_log2, kSUnitLog2);
                 static_assert(KP / 4 == 1 || KP / 4 == 2, "asm LDS-DMA: one or two K pieces per wave");
                 static_assert(VP / 4 == 2 * (KP / 4), "fp16 V image = two K tiles");
                 const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -1467,7 +1464,7 @@ sage_attn_kernel(const AttnParams p_arg)
                             SAGE_RENAME();
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
-                    } else {            // (D = 64: see the FP8 loop)
+                    } else {            // (D = 64 FP16 PV: the non-causal forms have no registers to spare under the three-waves limit for six bodies -- the run-time-slot body twice)
                         bool first_rt = true;
                         if ((n_steady - it) & 1) {           // odd count: one tile first, renamed (once per workgroup)
                             body(cur, first_rt, sA, sB, pA, pB);
@@ -1532,13 +1529,15 @@ sage_attn_kernel(const AttnParams p_arg)
 #undef A_FENCE
         }
     }
-    if constexpr (PERS_OK) {
-        // the general iterations' per-lane LDS offsets are re-derived here: formed before the pipelined loop they stay live across it, and the
-        // D = 64 per-thread instantiation with the folded score form then spills one of them (8 bytes of scratch for one store per item)
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        n = lane_t & 31;
-        g = lane_t >> 5;
+    if constexpr (MASK == 0) {
+        // the general iterations' and the epilogue's per-lane values (LDS offsets, the lane's row) are re-derived here from a lane index the
+        // compiler cannot see through: formed before the pipelined loops they stay live across them, and the D = 64 instantiations, which
+        // have no register to spare under their three-waves limit, spill them
+        asm volatile("" : "+v"(lane_g));
+        n = lane_g & 31;
+        g = lane_g >> 5;
+        my_row = row0 + n;
+        cmy_row = my_row - kchunk0;
     }
 #pragma nounroll
     for (; it < n_iters; it++) tile_iter(it);

@@ -58,4 +58,11 @@ call9() {   # loop trimming (row-sum definition by the first group; compile-time
   timeout 1700 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $out/pytest_parity.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_parity.log; filter < $out/pytest_parity.log | tail -6
 }
 
+call10() {   # six bodies at D = 64 FP8 too (lane values laundered behind the loops, ldexp for 2^26, plain PV MFMA in the general tiles): A/B + the whole GPU suite
+  out=gpurun_out/r6j; mkdir -p $out
+  for t in c5 e2e:c5 c3 e2e:c3 c2 e2e:c2; do timeout 300 python tools/lib_ab.py $t base main 2>&1 | filter | tee -a $out/trim_ab.txt; done
+  timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; filter < $out/pytest.log | tail -8
+  cp gpurun_out/parity_report.json $out/ 2>/dev/null
+}
+
 "$@"
