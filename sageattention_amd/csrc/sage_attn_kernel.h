@@ -48,6 +48,9 @@
 // replaces v_cvt_f32_i32; software-pipelined steady-state loops for FP8 and FP16 PV with their instruction order pinned in asm; FP8 PV on
 // v_mfma_f32_32x32x64_f8f6f4; two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only where a row maximum of
 // the wave moved; the ticket loop in the non-causal kernels and in the packed route's causal ones.
+#ifndef SAGE_ABL             // timing ablations of the FP8 pipelined loop (WRONG results; tools/build_variants.sh): 1 no O rescale, 2 no s_nop in
+#define SAGE_ABL 0           // front of the loop's MFMAs, 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
+#endif
 #ifndef SAGE_ATTN_TRACE      // tools/attn_trace.py: wave 0 of every workgroup records 100 MHz time stamps of its phases
 #define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
 #endif
@@ -905,10 +908,20 @@ sage_attn_kernel(const AttnParams p_arg)
             // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
             // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
             // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix of its block-scaled form (same products; 8 bytes and one VGPR less per MFMA)
-#define A_PV(acc, av, bv)  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#if SAGE_ABL & 2
+#define A_NOP_ ""
+#else
+#define A_NOP_ "s_nop 1\n\t"
+#endif
+#define A_PV(acc, av, bv)  asm volatile(A_NOP_ "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define A_QK0(acc, a, b)   asm volatile(A_NOP_ "v_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile(A_NOP_ "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
+#if SAGE_ABL & 16
+#define A_EXP_ "v_mov_b32"
+#else
+#define A_EXP_ "v_exp_f32"
+#endif
             if (it < n_steady) {
                 v16i sA[2], sB[2];
                 {
@@ -944,7 +957,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
                 float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
                 auto rescale = [&]() {
-                    if (__builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
+                    if ((SAGE_ABL & 1) == 0 && __builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
 #pragma unroll
                         for (int dt = 0; dt < C::DT; dt++)
 #pragma unroll
@@ -962,7 +975,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     const unsigned char *vs = smem + CUR * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    if ((SAGE_ABL & 4) == 0) __builtin_amdgcn_s_barrier();
                     {
                         // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
                         // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
@@ -1004,7 +1017,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                     for (int u = 0; u < 2; u++)
 #pragma unroll
-                        for (int i = 0; i < 16; i++) {
+                        for (int i = ((SAGE_ABL & 8) ? 14 : 0); i < 16; i++) {
                             if (KTHREAD && (i & 2)) mx1 = max(mx1, sc[u][i]);
                             else mx0 = max(mx0, sc[u][i]);
                         }
@@ -1073,7 +1086,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     auto g4a = [&](int w) {
                         const int sb = w >> 2, i0 = 4 * (w & 3);
 #define SAGE_G4A(SCALE4)                                                                                                                        \
-                        asm volatile(SCALE4 "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3"                        \
+                        asm volatile(SCALE4 A_EXP_ " %0, %0\n\t" A_EXP_ " %1, %1\n\t" A_EXP_ " %2, %2\n\t" A_EXP_ " %3, %3"                        \
                                      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)                                                                 \
                                      : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1))
                         if constexpr (SFOLD)
@@ -1169,6 +1182,8 @@ sage_attn_kernel(const AttnParams p_arg)
 #undef A_QK0
 #undef A_QK
 #undef A_FENCE
+#undef A_NOP_
+#undef A_EXP_
         } else {
             // ---- software-pipelined steady state, FP16 PV --------------------------------------------------------------------
             // Same structure as the FP8 loop above; differences:

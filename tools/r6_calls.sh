@@ -65,4 +65,10 @@ call10() {   # six bodies at D = 64 FP8 too (lane values laundered behind the lo
   cp gpurun_out/parity_report.json $out/ 2>/dev/null
 }
 
+call11() {   # timing ablations of the FP8 loop at D = 128 (WRONG results by construction): what each ingredient of a tile costs today
+  # built before the call: VARIANT_SRC="sage_attn_d128_f8.hip" tools/build_variants.sh abl1:"-DSAGE_ABL=1" abl2:"-DSAGE_ABL=2" abl4:"-DSAGE_ABL=4" abl8:"-DSAGE_ABL=8" abl16:"-DSAGE_ABL=16" abl31:"-DSAGE_ABL=31"
+  out=gpurun_out/r6k; mkdir -p $out
+  for t in c3 n32k; do SAGE_AB_ALLOW_DIFF=1 timeout 400 python tools/lib_ab.py $t main abl1 abl2 abl4 abl8 abl16 abl31 2>&1 | filter | tee -a $out/ablations.txt; done
+}
+
 "$@"
