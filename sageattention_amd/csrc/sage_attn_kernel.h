@@ -49,7 +49,7 @@
 // v_mfma_f32_32x32x64_f8f6f4; two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only where a row maximum of
 // the wave moved; the ticket loop in the non-causal kernels and in the packed route's causal ones.
 #ifndef SAGE_ABL             // timing ablations of the FP8 pipelined loop (WRONG results; tools/build_variants.sh): 1 no O rescale, 2 no s_nop in
-#define SAGE_ABL 0           // front of the loop's MFMAs, 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
+#define SAGE_ABL 0           // front of the loop's MFMAs (since they were dropped: 2 = WITH them), 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
 #endif
 #ifndef SAGE_ATTN_TRACE      // tools/attn_trace.py: wave 0 of every workgroup records 100 MHz time stamps of its phases
 #define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
@@ -908,10 +908,14 @@ sage_attn_kernel(const AttnParams p_arg)
             // Ring (3 slots): at the top of iteration t tile t+1 must have landed for every wave (its K is read now), and every
             // wave has finished reading tile t-1, whose slot takes the LDS-DMA of tile t+2.
             // the K = 64 FP8 MFMA without the v_mfma_ld_scale prefix of its block-scaled form (same products; 8 bytes and one VGPR less per MFMA)
+            // (no s_nop in front of these MFMAs since round 6 -- 0.7 % of a C3 launch, 24 + 16 nops per FP16 tile: no VALU instruction writes an operand of
+            //  theirs within two issue slots -- V / K fragments come from LDS behind the compiler's own waits, P from the previous tile's
+            //  conversions, O's rescale lies a barrier and the tile loads away; tools/mfma_hazard_lint.py checks exactly this rule on every listing,
+            //  copies the compiler might place in front of a statement included.  SAGE_ABL bit 2 puts the nops back.)
 #if SAGE_ABL & 2
-#define A_NOP_ ""
-#else
 #define A_NOP_ "s_nop 1\n\t"
+#else
+#define A_NOP_ ""
 #endif
 #define A_PV(acc, av, bv)  asm volatile(A_NOP_ "v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #define A_QK0(acc, a, b)   asm volatile(A_NOP_ "v_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
@@ -1203,9 +1207,20 @@ sage_attn_kernel(const AttnParams p_arg)
             //    Measured (profiles/r6_run_a_fp16_exact_lazy_ab.txt): exact scores cost the FP16 routes 4-5 % against round 5's folded bias, the lazy
             //    reference returns it (C2 -0.8 %, C4 causal +1.2 % against round 5; +4.2 % / +4.5 % against exact scores refreshed on every move).
 #define SAGE_SCALE2 SAGE_SCALE2_EXACT
-#define A_PV16(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#define A_QK0(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
-#define A_QK(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#if SAGE_ABL & 2
+#define A_NOP_ "s_nop 1\n\t"
+#else
+#define A_NOP_ ""                   // (see the FP8 loop)
+#endif
+#define A_PV16(acc, av, bv) asm volatile(A_NOP_ "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define A_QK0(acc, a, b)   asm volatile(A_NOP_ "v_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
+#define A_QK(acc, a, b)    asm volatile(A_NOP_ "v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+// ... with the nop: a work item's FIRST body, whose MFMAs read the zeros O and P start from -- the compiler materialises those where they are
+// first used, right in front of the asm MFMA (the lint's VALU-write rule found them) -- and every body of the D = 64 two-body form, whose
+// first body is a run-time case
+#define A_PV16N(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define A_QK0N(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
+#define A_QKN(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
             if (it < n_steady) {
                 v16i sA[2], sB[2];
@@ -1392,13 +1407,20 @@ sage_attn_kernel(const AttnParams p_arg)
                             kf[kk] = *reinterpret_cast<const v4i *>(ksn + krow * D + swz_chunk<D>(krow, 2 * kk + g) * 16);
                     };
                     auto &o_r = o;                   // (named in the generic body itself, as qfr below)
+                    constexpr bool NOPS = !SIX_BODIES || std::is_same<std::decay_t<decltype(first)>, std::true_type>::value;
                     auto pv4 = [&](int dt, v4i (&vf)[4], int c) {
-                        A_PV16(o_r[dt], vf[c], pp[c]);
+                        if constexpr (NOPS) A_PV16N(o_r[dt], vf[c], pp[c]);
+                        else A_PV16(o_r[dt], vf[c], pp[c]);
                     };
                     auto &qfr = qf;                  // (named in the generic body itself: a lambda nested in it does not capture through it otherwise)
                     auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
-                        else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
+                        if constexpr (NOPS) {
+                            if (kk == 0) A_QK0N(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
+                            else A_QKN(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
+                        } else {
+                            if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
+                            else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
+                        }
                     };
                     if constexpr (C::DT == 4) {
                         // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
@@ -1542,6 +1564,10 @@ sage_attn_kernel(const AttnParams p_arg)
 #undef A_QK0
 #undef A_QK
 #undef A_FENCE
+#undef A_NOP_
+#undef A_PV16N
+#undef A_QK0N
+#undef A_QKN
         }
     }
     if constexpr (MASK == 0) {

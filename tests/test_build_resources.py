@@ -108,6 +108,11 @@ def test_no_read_of_an_asm_issued_mfma_result_inside_its_latency():
     bad = "_Zk:\n\t;;#ASMSTART\n\tv_mfma_i32_32x32x32_i8 v[96:111], v[0:3], v[4:7], v[96:111]\n\t;;#ASMEND\n\tv_add_f32_e32 v1, v2, v3\n\tv_mov_b32_e32 v64, v97\n"
     ok = bad.replace("v_add_f32_e32 v1, v2, v3", "s_nop 15")
     assert len(lint.lint(bad)[0]) == 1 and len(lint.lint(ok)[0]) == 0
+    # ... the other direction (round 6: the loops' MFMAs carry no leading s_nop): a VALU write of an MFMA operand right in front of the MFMA
+    bad = "_Zk:\n\tv_mov_b32_e32 v5, v70\n\t;;#ASMSTART\n\tv_mfma_i32_32x32x32_i8 v[96:111], v[0:3], v[4:7], v[96:111]\n\t;;#ASMEND\n"
+    ok1 = bad.replace(";;#ASMSTART\n", ";;#ASMSTART\n\ts_nop 1\n")
+    ok2 = bad.replace("v_mov_b32_e32 v5, v70", "v_mov_b32_e32 v8, v70")
+    assert len(lint.lint(bad)[0]) == 1 and len(lint.lint(ok1)[0]) == 0 and len(lint.lint(ok2)[0]) == 0
     # ... and a VALU read of a transcendental's result in the next issue slot
     bad = "_Zk:\n\t;;#ASMSTART\n\tv_exp_f32 v3, v3\n\tv_add_f32 v1, v1, v3\n\t;;#ASMEND\n"
     ok = "_Zk:\n\t;;#ASMSTART\n\tv_exp_f32 v3, v3\n\tv_exp_f32 v4, v4\n\tv_add_f32 v1, v1, v3\n\t;;#ASMEND\n"

@@ -1337,6 +1337,31 @@ def test_causal_ragged_last_block_with_an_odd_count_of_pipelined_tiles(oracle_mo
         assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
 
 
+@pytest.mark.parametrize("ns", list(range(1, 15)))
+@pytest.mark.parametrize("pv,D", [("f16_two", 128), ("f16_single", 128), ("f16_single", 64), ("f8_two", 128), ("f8_two", 64)])
+def test_every_count_of_pipelined_tiles(oracle_mod, pv, D, ns):
+    """Non-causal, Lk = 64 (ns + 2): exactly `ns` tiles run through the software-pipelined loop -- since round 6 six bodies per trip (ring slot
+    and register set compile-time constants in each) and a remainder loop of up to five single bodies, each renamed behind it on the matrix
+    pipe (FP16 PV: behind a peeled first body).  ns = 1 ... 14 takes every remainder behind zero, one and two trips, in every loop form the
+    library instantiates (D = 64 FP16 PV keeps the two-body form)."""
+    Lk, Lq, dt = 64 * (ns + 2), 200, ns & 1
+    q, k, v = rand_qkv(1, 2, 2, Lq, Lk, D, dt, seed=1000 + ns, kbias=1.0)
+    fp8 = pv.startswith("f8")
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=False, pv="f8" if fp8 else "f16",
+                                                   qk_quant_gran="per_thread", return_lse=True, km=km,
+                                                   warpq=16 if (pv == "f16_two" and D == 128) else 32, fp8_scores=SCORES)
+    fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
+    o, lse = fn(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=False, qk_quant_gran="per_thread", pv_accum_dtype=PV_ACCUM[pv], return_lse=True)
+    torch.cuda.synchronize()
+    got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    assert np.isfinite(got).all()
+    assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{pv} D{D} ns{ns}: {err:.3e} vs {scale:.3e}"
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "100")))))
 def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     """The seeded sweep above for the entry points it does not reach: the Triton-named API (per-block scales, Q quantised in the kernel),

@@ -36,7 +36,8 @@ _REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 def listing(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "unit.s")
-        r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out],
+        r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", *os.environ.get("SAGE_LINT_FLAGS", "").split(), "-S",
+                            os.path.join(CSRC, src), "-o", out],
                            capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-2000:])
@@ -135,12 +136,45 @@ def _walk(ins, labels, start, pending, findings, top):
     return n_mfma
 
 
+VALU_TO_MFMA = 2           # wait states between a VALU write of a VGPR and an MFMA reading it as SrcA / SrcB / SrcC (cdna_hip_programming.md 5.7 item 2)
+
+
+def _valu_to_mfma(ins, findings):
+    """The other direction: an asm-issued MFMA whose operand a VALU instruction wrote fewer than VALU_TO_MFMA wait states before it.  The
+    pipelined loops issue their MFMAs without a leading s_nop (round 6: 12-24 nops per tile); that is sound only while nothing -- an asm
+    statement of ours or a copy the compiler places in front of one -- writes an operand right before the MFMA.  Follows the listing
+    (fall-through order; a label keeps the history: the body of a loop starts far from its first MFMA)."""
+    recent = []                # [wait states since, lo, hi, text] of VALU writes
+    kernel = None
+    for k, ln, line, op, ops, in_asm in ins:
+        if k != kernel:
+            kernel, recent = k, []
+        states = int(ops[0] or 0) + 1 if op == "s_nop" and ops else 1
+        if op.startswith("v_mfma"):
+            if in_asm:
+                for o in ops[1:4]:
+                    for a, b in _regs(o):
+                        for since, lo, hi, what in recent:
+                            if a <= hi and b >= lo and since < VALU_TO_MFMA:
+                                findings.add((kernel, ln, line, what + "  [VALU write -> MFMA operand]", VALU_TO_MFMA - since))
+        elif op.startswith("v_") and ops and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+            d = _regs(ops[0])
+            if d:
+                recent.append([-1, d[0][0], d[0][1], line])          # (-1: the increment below makes it 0 for the next instruction)
+            if op.startswith("v_permlane") and len(ops) > 1 and _regs(ops[1]):
+                recent.append([-1, _regs(ops[1])[0][0], _regs(ops[1])[0][1], line])
+        for r in recent:
+            r[0] += states
+        recent = [r for r in recent if r[0] < VALU_TO_MFMA]
+
+
 def lint(asm_text):
     """-> (list of findings, number of asm-issued MFMAs seen).  A finding: (kernel, line number, instruction, the MFMA, wait states short).
     The walk follows the listing and, with MFMAs pending at a branch, also the branch's target (loop back-edges, skipped blocks)."""
     ins, labels = _parse(asm_text)
     findings = set()
     n = _walk(ins, labels, 0, [], findings, True) if ins else 0
+    _valu_to_mfma(ins, findings)
     return sorted(findings, key=lambda f: f[1]), n
 
 

@@ -71,4 +71,10 @@ call11() {   # timing ablations of the FP8 loop at D = 128 (WRONG results by con
   for t in c3 n32k; do SAGE_AB_ALLOW_DIFF=1 timeout 400 python tools/lib_ab.py $t main abl1 abl2 abl4 abl8 abl16 abl31 2>&1 | filter | tee -a $out/ablations.txt; done
 }
 
+call12() {   # no leading s_nop in the loops' MFMAs (lint rule: VALU write -> MFMA operand): A/B against the library before + the parity suite incl. every tile count
+  out=gpurun_out/r6l; mkdir -p $out
+  for t in c3 c2 c2t c4 c5 n32k; do timeout 300 python tools/lib_ab.py $t base main 2>&1 | filter | tee -a $out/nonop_ab.txt; done
+  timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -q > $out/pytest_parity.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest_parity.log; filter < $out/pytest_parity.log | tail -6
+}
+
 "$@"
