@@ -197,6 +197,13 @@ def per_thread_case(name, B, Hq, Hkv, Lq, Lk, D, dtype, seed=0, BLKQ=128, WARPQ=
          meta=np.array([B, Hq, Hkv, Lq, Lk, D, 0 if dtype == torch.float16 else 1, 0], dtype=np.int64), **extra)
 
 
+def long_cases():
+    """Round 6: key ranges long enough for several trips of the kernels' six-body pipelined loop and a remainder behind them
+    (17 whole 64-key tiles + a ragged one; 1000 causal rows in 128-row blocks)."""
+    dense_case("long_nc_lq256_lk1100_d128_f16", 1, 2, 1, 256, 1100, 128, torch.float16, False, kbias=1.0, seed=16)
+    dense_case("long_c_n1000_d64_bf16", 1, 2, 2, 1000, 1000, 64, torch.bfloat16, True, kbias=0.5, seed=17)
+
+
 def per_thread_group_cases():
     f16, bf16 = torch.float16, torch.bfloat16
     per_thread_case("per_thread_sm90_d128_f16", 1, 2, 1, 200, 300, 128, f16, seed=13, BLKQ=64, WARPQ=16, BLKK=128, WARPK=128)
@@ -218,6 +225,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--per-thread-groups-only":
         per_thread_group_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--long-only":
+        long_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--varlen-cross-only":
         varlen_cross_case("varlenx_nc_d128_bf16", [100, 257, 64], [333, 64, 500], 4, 2, 128, bf16, False, seed=10)
         varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
@@ -237,3 +247,4 @@ if __name__ == "__main__":
     varlen_cross_case("varlenx_c_d64_f16", [200, 130, 70], [300, 130, 40], 4, 1, 64, f16, True, seed=11)
     mask_case("mask_bool_skipall_lq140_lk130_d64_f16", 1, 2, 1, 140, 130, 64, f16, "bool_skipall", seed=12)
     per_thread_group_cases()
+    long_cases()

@@ -678,7 +678,7 @@ def test_fp8_score_forms_exact_default_and_folded_variant(oracle_mod, case):
 
 # ------------------------------------------------------------------------------------------------ golden (reference outputs)
 @pytest.mark.parametrize("name", ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16",
-                                  "causal_n384d128_f16", "pad_d96_n160_f16"])
+                                  "causal_n384d128_f16", "pad_d96_n160_f16", "long_nc_lq256_lk1100_d128_f16", "long_c_n1000_d64_bf16"])
 @pytest.mark.parametrize("layout", ["HND", "NHD"])
 def test_triton_api_vs_reference_golden(name, layout):
     z, (B, Hq, Hkv, Lq, Lk, D, dt, causal) = util.golden(name)

@@ -6,7 +6,8 @@ import torch
 
 import util
 
-DENSE = ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16", "causal_n384d128_f16", "pad_d96_n160_f16"]
+DENSE = ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16", "causal_n384d128_f16", "pad_d96_n160_f16",
+         "long_nc_lq256_lk1100_d128_f16", "long_c_n1000_d64_bf16"]       # (round 6: key ranges of several trips of the kernels' six-body loop)
 VARLEN = ["varlen_nc_d64_f16", "varlen_c_d64_f16", "varlen_c_d128_bf16"]
 
 
