@@ -16,16 +16,18 @@
 //    v_permlane32_swap with the lane^32 partner.
 //  * P is converted in registers (v_cvt_pk_fp8_f32 / cvt f16) and is already the B operand of
 //    O^T = V^T P^T: the V pre-pass stores V^T tiles in the matching "position" order
-//    (sage_common.h), so P never goes through LDS.  FP8 PV runs on the block-scaled
-//    v_mfma_scale_f32_32x32x64_f8f6f4 with unit E8M0 scales: identical products and FP32
-//    accumulation, twice the rate of the non-scaled 32x32x16 fp8 MFMA.
-//  * one loop iteration covers NH 64-key images (NH = 2 -> 128 keys, the sm90 reference's tile):
-//    one row max, one rescale and one two-level fold per iteration; scales and masks stay per
-//    64-key block.  Two-level accumulation: the iteration's P.V product starts from a zero
-//    accumulator and is folded into the FP32 running output with one FMA (O = O*alpha + T).
-//  * K/V tiles are double-buffered in LDS and arrive by LDS-DMA (global_load_lds_dwordx4); the
+//    (sage_common.h), so P never goes through LDS.  FP8 PV runs on the K = 64 instruction
+//    v_mfma_f32_32x32x64_f8f6f4 (the plain form: no block scales), twice the rate of the 32x32x16 fp8 MFMA.
+//  * one loop iteration covers one 64-key image; scales and masks are per 64-key block.  Two-level
+//    accumulation: whole unmasked tiles add their P.V product to the FP32 running output through the
+//    MFMA's FP32 C operand (O = O*alpha + sum p v); general tiles start from a zero accumulator and fold
+//    it in with one FMA per element (O = O*alpha + T).
+//  * K/V tiles live in a 3-slot LDS ring and arrive by LDS-DMA (global_load_lds_dwordx4) two tiles ahead; the
 //    K image is XOR-swizzled through the per-lane SOURCE address, the V image is pre-swizzled
 //    by the pre-pass: every MFMA operand read is a conflict-free ds_read_b128.
+//  * whole unmasked tiles run software-pipelined loops whose instruction order is pinned in asm (six bodies
+//    per trip: ring slot and score-register set are compile-time constants in each); the last two tiles of a
+//    work item and every masked / ragged tile run the general, phased iteration (tile_iter).
 //  * output tile is transposed through (now free) LDS and stored as whole rows, 16 B per lane.
 #pragma once
 #include "sage_common.h"
