@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 20
+#define SAGE_ABI_VERSION 21
 
 #if defined(__GNUC__)
 #define SAGE_API __attribute__((visibility("default")))
@@ -441,6 +441,23 @@ SAGE_API int sage_attn_fused_qblock_pv_f16_vrows(const void *q, const int8_t *k,
                                                  int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                                                  int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
                                                  int is_causal, float q_premul, int out_dtype, void *stream, const SageLaunchAttr *attr);
+
+/* INT8 q / k with their scale tensors and V READ IN PLACE (ABI 21): argument for argument the reference's native FP16-PV ops --
+ *   qk_int8_sv_f16_accum_f32_attn / _f16_attn / _f16_attn_inst_buf / _f16_fuse_v_mean_attn(query i8, key i8, value f16, output, query_scale,
+ *   key_scale, [value_mean], tensor_layout, is_causal, qk_quant_gran, sm_scale, return_lse)   csrc/qattn/pybind_sm80.cpp:21-27, attn_cuda_sm80.h:19-65
+ * and the kernel-level entry of its Triton path, forward(q, k, v, q_scale, k_scale, ...) (sageattention/triton/attn_qk_int8_per_block.py:130,
+ * attn_qk_int8_per_block_causal.py:124: pv_accum = SAGE_PV_ACCUM_TRITON, qk_quant_gran = SAGE_GRAN_PER_BLOCK, sm_scale_log2 = 1) --
+ * with `value` the fp16 tensor itself ("value fp16, last dim contiguous", qk_int_sv_f16_cuda_sm80.cu:693-704): rows of D halves, element
+ * strides v_sb / v_sh / v_sl (multiples of 8), no tile image and no V pass in front of the call.  Same arguments as
+ * sage_attn_qk_int8_pv_f16 otherwise (v_mean: the per-channel mean the fuse_v_mean op adds back, or NULL); outputs and LSE bit-identical to
+ * it on the image of the same V.  Dense, unmasked; bf16 value tensors take the image entry (the reference converts them first, core.py:297-298). */
+SAGE_API int sage_attn_qk_int8_pv_f16_vrows(const int8_t *q, const int8_t *k, const void *v, void *o, float *lse,
+                                            const float *q_scale, const float *k_scale, const float *v_mean,
+                                            int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                            int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                            int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                            int is_causal, int qk_quant_gran, int q_warp,
+                                            float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr);
 
 /* The Triton-named API's attention (FP16 PV, tile product folded into the FP32 output, per-block k scales) with the PER-BLOCK Q
  * quantisation in the kernel prologue: q (fp16 / bf16) is multiplied by q_premul (= sm_scale * log2 e), one scale per 128 query rows,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAGE_GFX950_LIB") or os.path.join(_HERE, "libsage_gfx950.so")
 
 # mirrors of the header's constants
-ABI_VERSION = 20
+ABI_VERSION = 21
 DTYPE_F16, DTYPE_BF16 = 0, 1
 GRAN_PER_BLOCK, GRAN_PER_WARP, GRAN_PER_THREAD = 1, 2, 3
 GRAN_KBLK128 = 0x100          # OR-ed into the attention call's granularity: k scale groups of 128 keys
@@ -94,6 +94,8 @@ SYMBOLS = {   # (the trailing _P of every sage_attn_* entry point is `const Sage
                                         _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
                                          _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
+    "sage_attn_qk_int8_pv_f16_vrows": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                               _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _F, _I, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P, _P]),
     "sage_attn_qk_int8_pv_f16_varlen": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,

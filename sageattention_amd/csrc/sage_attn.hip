@@ -92,7 +92,8 @@ hipError_t launch_attn(const AttnParams &p_in, int head_dim, bool pv_fp8, bool c
     if (o.grid_out != nullptr) *o.grid_out = 0;
     if (nwork <= 0) return hipSuccess;
     if (mask_kind != 0 && (pv_fp8 || causal || kthread || mask_kind < 1 || mask_kind > 3)) return hipErrorInvalidValue;
-    const AttnVariant v = {causal, kthread, mask_kind != 0 ? true : two_level, mask_kind, 0, false};
+    if (p.v_rows != 0 && (pv_fp8 || mask_kind != 0 || p.cu_q != nullptr || p.kv_split > 1)) return hipErrorInvalidValue;
+    const AttnVariant v = {causal, kthread, mask_kind != 0 ? true : two_level, mask_kind, 0, p.v_rows != 0};
     return launch_unit(p, head_dim, pv_fp8, v, nwork, o);
 }
 

@@ -88,7 +88,7 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
         }
         return hipErrorInvalidValue;
     }
-    if (v.vrows) {                     // V rows read in place (fp16 inputs, FP16 PV, dense, fused Q quantisation): per-thread groups or per block
+    if (v.vrows) {                     // V rows read in place (fp16 V, FP16 PV, dense): fused Q quantisation per thread group / per block, or INT8 q
         if constexpr (!PV_FP8) {
             if (packed_list || p.cu_q != nullptr) return hipErrorInvalidValue;
 #define SAGE_VR(C_) \
@@ -96,6 +96,13 @@ hipError_t launch_attn_part(const AttnParams &p, const AttnVariant &v, int nwork
             if (v.causal == C_ && v.qf == 3) return launch_kernel<sage_attn_kernel<D, false, C_, false, true, NH, 0, 3, true, false, true>>(C::LDS_BYTES, p, nwork, l, pers);
             SAGE_VR(false) SAGE_VR(true)
 #undef SAGE_VR
+            // INT8 q with its scales (ABI 21, sage_attn_qk_int8_pv_f16_vrows): the reference's native FP16-PV ops as they are -- query / key INT8,
+            // value fp16 rows (pybind_sm80.cpp:21-27; the Triton forward, attn_qk_int8_per_block.py:130) -- in every k-scale grouping and both kernel forms
+#define SAGE_VR0(C_, K_, T_) if (v.qf == 0 && v.causal == C_ && v.kthread == K_ && v.two_level == T_) \
+            return launch_kernel<sage_attn_kernel<D, false, C_, K_, T_, NH, 0, 0, true, false, true>>(C::LDS_BYTES, p, nwork, l, pers);
+            SAGE_VR0(false, false, false) SAGE_VR0(false, false, true) SAGE_VR0(true, false, false) SAGE_VR0(true, false, true)
+            SAGE_VR0(false, true, false)  SAGE_VR0(false, true, true)  SAGE_VR0(true, true, false)  SAGE_VR0(true, true, true)
+#undef SAGE_VR0
         }
         return hipErrorInvalidValue;
     }

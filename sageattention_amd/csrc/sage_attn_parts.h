@@ -13,7 +13,7 @@ struct AttnVariant {
     bool two_level;     // FP8 PV: tile product from a zero accumulator; FP16 PV: the Triton kernel form (SAGE_PV_ACCUM_TRITON)
     int mask_kind;      // 0 none, 1 bool, 2 additive fp16, 3 additive bf16 (FP16 PV, per-block scales, non-causal)
     int qf;             // 0: INT8 q + q_scale; 1 / 2: fp16 / bf16 q quantised per thread group in the prologue; 3 / 4: per 128-row block
-    bool vrows;         // FP16 PV, qf 1 / 3, dense: AttnParams::v is the caller's fp16 V (rows, v_sb / v_sh / v_sl), not the tile image
+    bool vrows;         // FP16 PV, qf 0 / 1 / 3, dense, unmasked: AttnParams::v is the caller's fp16 V (rows, v_sb / v_sh / v_sl), not the tile image
 };
 
 // D in {64, 128}; PV_FP8; SFOLD: the FP8 score form (true = folded bias, false = exact subtraction; FP16 PV has one form: true)

@@ -74,10 +74,15 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
                 int64_t o_sb, int64_t o_sh, int64_t o_sl,
                 int is_causal, int gran, int q_warp, float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr,
                 const MaskArg *mask = nullptr, const int32_t *seq_order = nullptr,
-                const int32_t *work_items = nullptr, const int32_t *work_hdr = nullptr, int items_bound = 0)
+                const int32_t *work_items = nullptr, const int32_t *work_hdr = nullptr, int items_bound = 0, const int64_t *v_strides = nullptr)
 {
     LaunchAttr la;
     if (const int rc = read_attr(attr, stream, mask == nullptr, la)) return rc;
+    if (v_strides != nullptr) {            // `v_image` is the caller's fp16 value tensor itself (rows), read in place
+        SAGE_REQUIRE(!fp8 && !varlen && mask == nullptr, "V rows in place: dense, unmasked FP16-PV calls");
+        SAGE_REQUIRE(v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 && v_strides[2] % 8 == 0 && v_strides[2] >= D, "v strides must be multiples of 8 elements (16-byte rows)");
+        SAGE_REQUIRE(((int64_t)(Lk - 1) * v_strides[2] + D) * 2 < (int64_t)1 << 31, "one head of v must span less than 2 GiB");
+    }
     SAGE_REQUIRE(q && k && v_image && o && q_scale && k_scale, "null tensor pointer");
     SAGE_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128 (got %d); pad on the host as core.py:260-271 does", D);
     SAGE_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Lq > 0, "empty problem (B=%d Hq=%d Hkv=%d Lq=%d)", B, Hq, Hkv, Lq);
@@ -127,6 +132,7 @@ int attn_common(bool fp8, bool varlen, const int8_t *q, const int8_t *k, const v
     p.out_dtype = out_dtype;
     p.lse_sh = 0;
     p.sm_scale_log2 = sm_scale_log2;
+    if (v_strides != nullptr) { p.v_rows = 1; p.v_sb = v_strides[0]; p.v_sh = v_strides[1]; p.v_sl = v_strides[2]; }
     int mask_kind = 0;
     if (mask != nullptr) {
         SAGE_REQUIRE(mask->ptr, "null attn_mask pointer");
@@ -614,6 +620,20 @@ SAGE_API int sage_attn_qk_int8_pv_f16(const int8_t *q, const int8_t *k, const vo
     return attn_common(false, false, q, k, v_image, o, lse, q_scale, k_scale, nullptr, v_mean, nullptr, nullptr, nullptr, nullptr,
                        B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
                        is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream, attr);
+}
+
+SAGE_API int sage_attn_qk_int8_pv_f16_vrows(const int8_t *q, const int8_t *k, const void *v, void *o, float *lse,
+                                   const float *q_scale, const float *k_scale, const float *v_mean,
+                                   int B, int Hq, int Hkv, int Lq, int Lk, int D,
+                                   int64_t q_sb, int64_t q_sh, int64_t q_sl, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                                   int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t o_sb, int64_t o_sh, int64_t o_sl,
+                                   int is_causal, int qk_quant_gran, int q_warp,
+                                   float sm_scale_log2, int pv_accum, int out_dtype, void *stream, const SageLaunchAttr *attr)
+{
+    const int64_t vs[3] = {v_sb, v_sh, v_sl};
+    return attn_common(false, false, q, k, v, o, lse, q_scale, k_scale, nullptr, v_mean, nullptr, nullptr, nullptr, nullptr,
+                       B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,
+                       is_causal, qk_quant_gran, q_warp, sm_scale_log2, pv_accum, out_dtype, stream, attr, nullptr, nullptr, nullptr, nullptr, 0, vs);
 }
 
 SAGE_API int sage_attn_qk_int8_pv_f16_masked(const int8_t *q, const int8_t *k, const void *v_image, void *o, float *lse,

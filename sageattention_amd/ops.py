@@ -151,13 +151,25 @@ def qk_int8_sv_f16_attn_impl(query: torch.Tensor, key: torch.Tensor, v_image: to
                         query_scale: torch.Tensor, key_scale: torch.Tensor, value_mean: Optional[torch.Tensor],
                         tensor_layout: int, is_causal: int, qk_quant_gran: int, q_warp: int, sm_scale_log2: float,
                         pv_accum: int, return_lse: int) -> torch.Tensor:
-    """INT8 QK^T + FP16 PV (replaces the sm80 ops, sm80_compile.py:5-149, and the Triton forward)."""
+    """INT8 QK^T + FP16 PV (replaces the sm80 ops, sm80_compile.py:5-149, and the Triton forward).  ``v_image``: the gfx950 tile image
+    (5-D, ``quant.prep_v_fp16`` / the fused pre-pass) -- or, as the reference's ops take it, the fp16 value tensor itself in the layout of
+    ``key`` (4-D; ``sage_attn_qk_int8_pv_f16_vrows``: rows read in place, same bits)."""
     B, Hq, Lq, D, q_sb, q_sh, q_sl = _dims(query, tensor_layout)
     _, Hkv, Lk, _, k_sb, k_sh, k_sl = _dims(key, tensor_layout)
     _, _, _, _, o_sb, o_sh, o_sl = _dims(output, tensor_layout)
     lse = _lse_alloc(query, tensor_layout, return_lse)
     code = _cabi.DTYPE_F16 if output.dtype == torch.float16 else _cabi.DTYPE_BF16
     attr = attn_attr(query.device, is_causal, B * Hq * ((Lq + 127) // 128))
+    if v_image.dim() == 4:
+        assert v_image.dtype == torch.float16 and v_image.stride(-1) == 1, "value read in place: fp16, last dimension contiguous"
+        _, _, _, _, v_sb, v_sh, v_sl = _dims(v_image, tensor_layout)
+        rc = _cabi.load().sage_attn_qk_int8_pv_f16_vrows(
+            _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
+            _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl,
+            is_causal, qk_quant_gran, q_warp, float(sm_scale_log2), pv_accum, code,
+            torch._C._cuda_getCurrentRawStream(output.device.index), _cabi.attr_arg(attr))
+        attn_check(rc, "sage_attn_qk_int8_pv_f16_vrows", attr, query.device)
+        return lse
     rc = _cabi.load().sage_attn_qk_int8_pv_f16(
         _p(query), _p(key), _p(v_image), _p(output), _p(lse) if return_lse else None, _p(query_scale), _p(key_scale),
         _p(value_mean), B, Hq, Hkv, Lq, Lk, D, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, o_sb, o_sh, o_sl,

@@ -600,6 +600,114 @@ def test_v_rows_in_place_is_bit_identical_to_the_tile_image_route(api, layout, s
     assert not calls
 
 
+@pytest.mark.parametrize("gran,accum", [("per_block", "triton"), ("per_block", "cuda"), ("per_warp", "cuda"), ("per_thread", "cuda")])
+@pytest.mark.parametrize("shape", VROWS_SHAPES, ids=[f"b{a}h{b}k{c}q{d}l{e}d{f}" for a, b, c, d, e, f in VROWS_SHAPES])
+@pytest.mark.parametrize("layout,causal", [("HND", False), ("NHD", True)])
+def test_int8_q_v_rows_in_place_is_bit_identical_to_the_tile_image(shape, layout, causal, gran, accum):
+    """ABI 21, ``sage_attn_qk_int8_pv_f16_vrows``: the reference's native FP16-PV op signature (INT8 q / k, their scales, the fp16 value tensor
+    as it is) against the image entry point on the image of the same V -- same operands into the same MFMAs, bit for bit, in every scale
+    grouping and both kernel forms."""
+    B, Hq, Hkv, Lq, Lk, D = shape
+    if causal and Lq != Lk:
+        pytest.skip("causal needs Lq == Lk")
+    q, k, v = rand_qkv(B, Hq, Hkv, Lq, Lk, D, 0, seed=Lq + Lk + D, kbias=1.0)
+    q, k, v = to_dev(q, layout), to_dev(k, layout), to_dev(v, layout)
+    km = sq.channel_mean(k, layout)
+    km4 = km.unsqueeze(1 if layout == "NHD" else 2)
+    if gran == "per_block":
+        q8, qs, k8, ks = sq.per_block_int8(q, k, km=km4, sm_scale=D ** -0.5, tensor_layout=layout)
+        g, warp, sml2 = _cabi.GRAN_PER_BLOCK, 128, 1.0
+    elif gran == "per_warp":
+        q8, qs, k8, ks = sq.per_warp_int8(q, k, km=km4, tensor_layout=layout)
+        g, warp, sml2 = _cabi.GRAN_PER_WARP, 32, D ** -0.5 * sq.LOG2E
+    else:
+        q8, qs, k8, ks = sq.per_thread_int8(q, k, km=km4, tensor_layout=layout)
+        g, warp, sml2 = _cabi.GRAN_PER_THREAD, 32, D ** -0.5 * sq.LOG2E
+    acc = _cabi.PV_ACCUM_TRITON if accum == "triton" else _cabi.PV_ACCUM_SINGLE
+    lay = 0 if layout == "NHD" else 1
+    outs = []
+    for vv in (sq.prep_v_fp16(v, layout), v):
+        o = torch.empty(q.shape, dtype=torch.float16, device=DEV)
+        lse = sa_ops.qk_int8_sv_f16_attn_impl(q8, k8, vv, o, qs, ks, None, lay, int(causal), g, warp, sml2, acc, 1)
+        torch.cuda.synchronize()
+        outs.append((o, lse))
+    assert torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name", ["c1_b1h4n512d64_f16", "gqa_causal_n300d128_bf16", "cross_lq200_lk333_d64_f16", "causal_n384d128_f16",
+                                  "long_nc_lq256_lk1100_d128_f16", "long_c_n1000_d64_bf16"])
+def test_kernel_level_forward_on_the_reference_s_own_int8_operands(name):
+    """``sageattention.triton.attn_qk_int8_per_block[_causal].forward`` -- the reference's kernel-level entry (what its bench script times) -- fed the
+    INT8 tensors and scales the REFERENCE's quantiser produced (in the fixture), against the reference kernel's own output: the attention
+    kernel alone, pinned to a reference output with nothing of ours in front of it."""
+    from sageattention.triton.attn_qk_int8_per_block import forward
+    from sageattention.triton.attn_qk_int8_per_block_causal import forward as forward_causal
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, causal) = util.golden(name)
+    q8, k8 = torch.from_numpy(z["q_int8"]).to(DEV), torch.from_numpy(z["k_int8"]).to(DEV)
+    qs, ks = torch.from_numpy(z["q_scale"]).to(DEV), torch.from_numpy(z["k_scale"]).to(DEV)
+    v = util.from_bits(z["v"], dt, DEV).to(torch.float16)            # core.py:297-298
+    odt = torch.float16 if dt == 0 else torch.bfloat16
+    o, lse = (forward_causal if causal else forward)(q8, k8, v, qs, ks, output_dtype=odt, return_lse=True)
+    torch.cuda.synchronize()
+    assert o.dtype == odt and o.shape == q8.shape and lse.shape == (B, Hq, Lq)
+    got, ref = o.float().cpu().numpy(), util.f32(z["o"], dt)
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
+    o2, lse2 = (forward_causal if causal else forward)(q8, k8, v, qs.half().unsqueeze(-1), ks.half().unsqueeze(-1), output_dtype=odt)   # (scale tensors as the reference's bench script hands them)
+    assert lse2.numel() == 0 and o2.shape == o.shape
+
+
+@pytest.mark.parametrize("name", ["varlen_nc_d64_f16", "varlen_c_d64_f16", "varlen_c_d128_bf16", "varlenx_nc_d128_bf16", "varlenx_c_d64_f16"])
+def test_kernel_level_varlen_forward_on_the_reference_s_own_int8_operands(name):
+    """The packed counterparts (attn_qk_int8_block_varlen.forward / attn_qk_int8_per_block_causal_varlen.forward) on the reference quantiser's tensors."""
+    from sageattention.triton.attn_qk_int8_block_varlen import forward
+    from sageattention.triton.attn_qk_int8_per_block_causal_varlen import forward as forward_causal
+    z, meta = util.golden(name)
+    dt, causal, D = meta[6], meta[7], meta[5]
+    cu_q = torch.from_numpy(z["cu_q"] if "cu_q" in z.files else z["cu"]).to(torch.int32).to(DEV)
+    cu_k = torch.from_numpy(z["cu_k"] if "cu_k" in z.files else z["cu"]).to(torch.int32).to(DEV)
+    q8, k8 = torch.from_numpy(z["q_int8"]).to(DEV), torch.from_numpy(z["k_int8"]).to(DEV)
+    qs, ks = torch.from_numpy(z["q_scale"]).to(DEV), torch.from_numpy(z["k_scale"]).to(DEV)
+    cu_qs, cu_ks = torch.from_numpy(z["cu_qs"]).to(torch.int32).to(DEV), torch.from_numpy(z["cu_ks"]).to(torch.int32).to(DEV)
+    v = util.from_bits(z["v"], dt, DEV).to(torch.float16)
+    max_q = int((cu_q[1:] - cu_q[:-1]).max().item())
+    odt = torch.float16 if dt == 0 else torch.bfloat16
+    o = (forward_causal if causal else forward)(q8, k8, v, cu_q, cu_k, max_q, qs, ks, cu_qs, cu_ks, output_dtype=odt)
+    torch.cuda.synchronize()
+    got, ref = o.float().cpu().numpy(), util.f32(z["o"], dt)
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-3 * scale + (2 ** -7 * scale if dt == 1 else 0.0)
+
+
+def test_reference_module_names_import_and_quantise_like_the_reference():
+    """``sageattention.core`` / ``.quant`` / ``.triton.*``: the reference's module paths resolve, with its signatures; the quantisers behind them return
+    the reference's bits (the per-block fixture) and the CUDA-convention one differs from the Triton one only in rounding."""
+    import sageattention.core as rc
+    import sageattention.quant as rq
+    from sageattention.triton.quant_per_block import per_block_int8
+    from sageattention.triton.quant_per_thread import per_thread_int8
+    from sageattention.triton.quant_per_block_varlen import per_block_int8 as per_block_int8_varlen
+    assert rc.sageattn is sa.sageattn and rc.sageattn_varlen is sa.sageattn_varlen
+    z, (B, Hq, Hkv, Lq, Lk, D, dt, causal) = util.golden("c1_b1h4n512d64_f16")
+    q, k = util.from_bits(z["q"], dt, DEV), util.from_bits(z["k"], dt, DEV)
+    km = util.from_bits(z["km"], dt, DEV)
+    q8, qs, k8, ks = per_block_int8(q, k, km=km, sm_scale=D ** -0.5)
+    assert (q8.cpu().numpy() == z["q_int8"]).all() and (k8.cpu().numpy() == z["k_int8"]).all()
+    assert (qs.cpu().numpy() == z["q_scale"]).all() and (ks.cpu().numpy() == z["k_scale"]).all()
+    q8c, qsc, k8c, ksc = rq.per_block_int8(q, k, km=km, sm_scale=D ** -0.5)
+    assert (q8c.int() - q8.int()).abs().max().item() <= 1 and q8c.shape == q8.shape
+    assert rq.per_warp_int8(q, k, km=km)[1].shape == (B, Hq, 4 * ((Lq + 127) // 128))
+    assert per_thread_int8(q, k, km=km)[3].shape == (B, Hkv, 4 * ((Lk + 63) // 64))
+    zv, _ = util.golden("varlen_c_d64_f16")
+    qv, kv = util.from_bits(zv["q"], 0, DEV), util.from_bits(zv["k"], 0, DEV)
+    cu = torch.from_numpy(zv["cu"]).to(torch.int32).to(DEV)
+    kv = kv - kv.mean(dim=0, keepdim=True)                              # core.py:432-434
+    r = per_block_int8_varlen(qv, kv, cu, cu, 257, 257, sm_scale=64 ** -0.5)
+    assert len(r) == 6 and (r[0].cpu().numpy() == zv["q_int8"]).all() and (r[2].cpu().numpy() == zv["k_int8"]).all()
+    assert (r[4].cpu().numpy() == zv["cu_qs"]).all() and (r[5].cpu().numpy() == zv["cu_ks"]).all()
+
+
 def test_strided_views_of_a_packed_qkv_tensor():
     """q/k/v as non-contiguous views (the usual fused-QKV projection output): strides are honoured, no copies."""
     g = torch.Generator().manual_seed(3)

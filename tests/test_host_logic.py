@@ -16,6 +16,29 @@ def test_public_names_match_reference():
     assert sageattention.sageattn is sa.sageattn
 
 
+def test_reference_module_paths_and_signatures():
+    """The reference's module paths (sageattention/core.py, quant.py, triton/*.py) resolve to the gfx950 implementation with the reference's
+    parameter names and defaults; the kernel-level entry points reject CPU tensors instead of emulating."""
+    import inspect
+    import sageattention.core as rc
+    import sageattention.quant as rq
+    from sageattention.triton import (attn_qk_int8_per_block, attn_qk_int8_per_block_causal, attn_qk_int8_block_varlen,
+                                      attn_qk_int8_per_block_causal_varlen, quant_per_block, quant_per_block_varlen, quant_per_thread)
+    assert rc.sageattn is sa.sageattn and rc.sageattn_qk_int8_pv_fp8_cuda_sm90 is sa.sageattn_qk_int8_pv_fp8_cuda_sm90
+    par = lambda f: list(inspect.signature(f).parameters)
+    assert par(attn_qk_int8_per_block.forward) == ["q", "k", "v", "q_scale", "k_scale", "tensor_layout", "attn_mask", "output_dtype", "return_lse"]   # attn_qk_int8_per_block.py:130
+    assert par(attn_qk_int8_per_block_causal.forward) == ["q", "k", "v", "q_scale", "k_scale", "tensor_layout", "output_dtype", "return_lse"]       # _causal.py:124
+    vl = ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "q_scale", "k_scale", "cu_seqlens_q_scale", "cu_seqlens_k_scale", "output_dtype"]
+    assert par(attn_qk_int8_block_varlen.forward) == vl and par(attn_qk_int8_per_block_causal_varlen.forward) == vl                                  # :123, :138
+    assert par(quant_per_block.per_block_int8) == ["q", "k", "km", "BLKQ", "BLKK", "sm_scale", "tensor_layout"] == par(rq.per_block_int8)          # quant_per_block.py:49, quant.py:22
+    assert par(quant_per_block_varlen.per_block_int8) == ["q", "k", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "BLKQ", "BLKK", "sm_scale"]
+    assert par(quant_per_thread.per_thread_int8) == ["q", "k", "km", "BLKQ", "WARPQ", "BLKK", "WARPK", "sm_scale", "tensor_layout"]                 # quant_per_thread.py:154
+    assert par(rq.per_warp_int8) == ["q", "k", "km", "BLKQ", "WARPQ", "BLKK", "tensor_layout"] and callable(rq.sub_mean) and callable(rq.per_channel_fp8)
+    q8 = torch.zeros(1, 1, 8, 64, dtype=torch.int8)
+    with pytest.raises(AssertionError):
+        attn_qk_int8_per_block.forward(q8, q8, torch.zeros(1, 1, 8, 64, dtype=torch.float16), torch.ones(1, 1, 1), torch.ones(1, 1, 1))
+
+
 def test_cpu_tensors_are_rejected_not_emulated():
     q = torch.zeros(1, 1, 8, 64, dtype=torch.float16)
     with pytest.raises(ValueError, match="Unsupported architecture"):
