@@ -4,9 +4,14 @@ the CUDA rounding convention (quant.py:22-103); the Triton one lives in ``sageat
 private to (quantiser, kernel) pairs of one implementation (include/sage_gfx950.h)."""
 from typing import Optional
 
-from sageattention_amd.quant import per_warp_int8, per_channel_fp8, sub_mean          # noqa: F401
+from sageattention_amd.quant import per_warp_int8, sub_mean          # noqa: F401
+from sageattention_amd.quant import per_channel_fp8 as _per_channel_fp8
 from sageattention_amd.quant import per_block_int8 as _per_block_int8
 
 
 def per_block_int8(q, k, km=None, BLKQ: int = 128, BLKK: int = 64, sm_scale: Optional[float] = None, tensor_layout: str = "HND"):
     return _per_block_int8(q, k, km=km, BLKQ=BLKQ, BLKK=BLKK, sm_scale=sm_scale, tensor_layout=tensor_layout, quantization_backend="cuda")
+
+
+def per_channel_fp8(v, tensor_layout: str = "HND", scale_max: float = 448.0, smooth_v: bool = True):      # (the reference's defaults, quant.py:224-229)
+    return _per_channel_fp8(v, tensor_layout=tensor_layout, scale_max=scale_max, smooth_v=smooth_v)

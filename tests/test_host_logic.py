@@ -33,7 +33,8 @@ def test_reference_module_paths_and_signatures():
     assert par(quant_per_block.per_block_int8) == ["q", "k", "km", "BLKQ", "BLKK", "sm_scale", "tensor_layout"] == par(rq.per_block_int8)          # quant_per_block.py:49, quant.py:22
     assert par(quant_per_block_varlen.per_block_int8) == ["q", "k", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "BLKQ", "BLKK", "sm_scale"]
     assert par(quant_per_thread.per_thread_int8) == ["q", "k", "km", "BLKQ", "WARPQ", "BLKK", "WARPK", "sm_scale", "tensor_layout"]                 # quant_per_thread.py:154
-    assert par(rq.per_warp_int8) == ["q", "k", "km", "BLKQ", "WARPQ", "BLKK", "tensor_layout"] and callable(rq.sub_mean) and callable(rq.per_channel_fp8)
+    assert par(rq.per_warp_int8) == ["q", "k", "km", "BLKQ", "WARPQ", "BLKK", "tensor_layout"] and par(rq.sub_mean) == ["v", "tensor_layout"]
+    assert inspect.signature(rq.per_channel_fp8).parameters["smooth_v"].default is True and par(rq.per_channel_fp8) == ["v", "tensor_layout", "scale_max", "smooth_v"]   # quant.py:224-229
     q8 = torch.zeros(1, 1, 8, 64, dtype=torch.int8)
     with pytest.raises(AssertionError):
         attn_qk_int8_per_block.forward(q8, q8, torch.zeros(1, 1, 8, 64, dtype=torch.float16), torch.ones(1, 1, 1), torch.ones(1, 1, 1))
