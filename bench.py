@@ -468,8 +468,19 @@ def measure_triton_api(cfg, q, k, v, steps, warmup, ramp):
     kern_ms = sum(dev_k) / len(dev_k)
     n = max(3, steps // 2)
     wall, _ = timed(lambda: sa.sageattn_qk_int8_pv_fp16_triton(q, k, v, is_causal=cfg["causal"]), n, 2, False, ramp)
+    # the reference's kernel-level entry under the reference's module path (what its bench/bench_qk_int8_pv_fp16_triton.py imports and times):
+    # INT8 q / k with their scales and the fp16 value tensor in -- V read in place (ABI 21), nothing in front of the kernel
+    from sageattention.triton.attn_qk_int8_per_block import forward as ref_forward
+    from sageattention.triton.attn_qk_int8_per_block_causal import forward as ref_forward_causal
+    q8, qs, _, _ = sq.per_block_int8(q, k, sm_scale=sm, tensor_layout="HND", k_done=(k8, ks))      # (the Q half; K comes smoothed from the pre-pass above)
+    fwd = ref_forward_causal if cfg["causal"] else ref_forward
+    _, dev_f = timed(lambda: fwd(q8, k8, v, qs, ks, output_dtype=q.dtype), steps, warmup, False, ramp)
+    fwd_ms = sum(dev_f) / len(dev_f)
     return {"workload": "sageattn_qk_int8_pv_fp16_triton at the C2 shape (B=2 H=32 N=4096 D=128 causal, fp16)",
             "kernel_only": {"ms_per_launch": round(kern_ms, 4), "tflops": round(fl / kern_ms / 1e9, 2)},
+            "kernel_level_forward": {"ms_per_call": round(fwd_ms, 4), "tflops": round(fl / fwd_ms / 1e9, 2),
+                                     "what": "sageattention.triton.attn_qk_int8_per_block_causal.forward(q_int8, k_int8, v, q_scale, k_scale): the reference's "
+                                             "kernel-level API and signature, INT8 operands, fp16 value rows read in place (sage_attn_qk_int8_pv_f16_vrows)"},
             "roofline": roofline_obj(fl, kern_ms, "fp16", "sage_attn_kernel (per-block Q quantised in the prologue, Triton kernel form" + (", V rows in place)" if rows else ")"), "c2t"),
             "end_to_end": {"ms_per_call": round(wall / n * 1e3, 4), "tflops": round(fl / (wall / n) / 1e12, 2)}}
 
