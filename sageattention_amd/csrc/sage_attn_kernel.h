@@ -53,6 +53,9 @@
 #ifndef SAGE_ABL             // timing ablations of the FP8 pipelined loop (WRONG results; tools/build_variants.sh): 1 no O rescale, 2 no s_nop in
 #define SAGE_ABL 0           // front of the loop's MFMAs (since they were dropped: 2 = WITH them), 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
 #endif
+#ifndef SAGE_KSEL            // pipelined loops, per-thread k scale groups: the lane halves' scale products under EXEC (1) or by select (0: A/B)
+#define SAGE_KSEL 1
+#endif
 #ifndef SAGE_ATTN_TRACE      // tools/attn_trace.py: wave 0 of every workgroup records 100 MHz time stamps of its phases
 #define SAGE_ATTN_TRACE 0    // (entry, geometry known, Q ready, first tile landed, key loop done, epilogue barrier, stores issued, stores acknowledged)
 #endif
@@ -1011,8 +1014,15 @@ sage_attn_kernel(const AttnParams p_arg)
                     //  the K-fragment reads and the scalar load of the next K scales are issued behind it)
                     A_PV(o[0], vf[0], pp);
                     A_FENCE();
+                    // the next tile's k scales (scalar loads).  Per-thread groups: the lane halves take different pairs of the tile's four scales;
+                    // the products with the lane's q scale are formed under EXEC instead of selecting first (SAGE_KSEL: three VALU
+                    // instructions per tile less than move + select + multiply; same multiplications in the same order: same bits)
                     float ksc_next[NH][2];
-                    load_kscales(it + 1, ksc_next);
+                    [[maybe_unused]] float ks4[4];
+                    if constexpr (KTHREAD && SAGE_KSEL) {
+                        const long tb = (long)((it + 1) >> p.ks_shift) * ks_tstride;      // (whole tiles only in this loop: it + 1 < ntk_all)
+                        ks4[0] = ks_c[tb]; ks4[1] = ks_c[tb + 1]; ks4[2] = ks_c[tb + 2]; ks4[3] = ks_c[tb + 3];
+                    } else load_kscales(it + 1, ksc_next);
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
 #pragma unroll
                     for (int kk = 0; kk < C::KSTEPS; kk++) {
@@ -1144,8 +1154,19 @@ sage_attn_kernel(const AttnParams p_arg)
                         grp(13); grp(14); grp(15);
                     }
                     l_run = l_run * alpha + (rs0 + rs1);
-                    cs[0] = sm26 * (qsc * ksc_next[0][0]);
-                    cs[1] = KTHREAD ? sm26 * (qsc * ksc_next[0][1]) : cs[0];
+                    if constexpr (KTHREAD && SAGE_KSEL) {
+                        unsigned long long keep;
+                        asm volatile("v_mul_f32 %0, %3, %7\n\tv_mul_f32 %1, %4, %7\n\t"
+                                     "s_mov_b64 %2, exec\n\ts_mov_b64 exec, %8\n\t"
+                                     "v_mul_f32 %0, %5, %7\n\tv_mul_f32 %1, %6, %7\n\t"
+                                     "s_mov_b64 exec, %2\n\t"
+                                     "v_mul_f32 %0, %9, %0\n\tv_mul_f32 %1, %9, %1"
+                                     : "=&v"(cs[0]), "=&v"(cs[1]), "=&s"(keep)
+                                     : "s"(ks4[0]), "s"(ks4[1]), "s"(ks4[2]), "s"(ks4[3]), "v"(qsc), "s"(0xFFFFFFFF00000000ull), "v"(sm26));
+                    } else {
+                        cs[0] = sm26 * (qsc * ksc_next[0][0]);
+                        cs[1] = KTHREAD ? sm26 * (qsc * ksc_next[0][1]) : cs[0];
+                    }
                     alpha_p = alpha;
                     it++;
                 };
@@ -1252,6 +1273,13 @@ sage_attn_kernel(const AttnParams p_arg)
                 [[maybe_unused]] const unsigned voff16 = lane * 16;
                 const unsigned koff1m = (KP / 4 == 2) ? koff[KP / 4 - 1] - 1024u : 0u;
                 constexpr float kLazyTau = 8.0f;
+                // per-thread k scale groups: the tile's four scales stay scalars from body to body and their products with the lane's q scale are
+                // formed under EXEC (SAGE_KSEL, see the FP8 loop); `ksc` is restored from them behind the loop for the general tiles
+                [[maybe_unused]] float ks4c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (KTHREAD && SAGE_KSEL) {
+                    const long tb = (long)(it >> p.ks_shift) * ks_tstride;
+                    ks4c[0] = ks_c[tb]; ks4c[1] = ks_c[tb + 1]; ks4c[2] = ks_c[tb + 2]; ks4c[3] = ks_c[tb + 3];
+                }
                 float alpha_p = 1.0f;
                 bool moved_p = false;              // wave-uniform: the previous tile refreshed the reference, O owes alpha_p
                 auto rescale = [&]() {
@@ -1326,8 +1354,19 @@ sage_attn_kernel(const AttnParams p_arg)
                         }
                     }
                     float cs[2];
-                    cs[0] = sm26 * (qsc * ksc[0][0]);
-                    cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
+                    if constexpr (KTHREAD && SAGE_KSEL) {
+                        unsigned long long keep;
+                        asm volatile("v_mul_f32 %0, %3, %7\n\tv_mul_f32 %1, %4, %7\n\t"
+                                     "s_mov_b64 %2, exec\n\ts_mov_b64 exec, %8\n\t"
+                                     "v_mul_f32 %0, %5, %7\n\tv_mul_f32 %1, %6, %7\n\t"
+                                     "s_mov_b64 exec, %2\n\t"
+                                     "v_mul_f32 %0, %9, %0\n\tv_mul_f32 %1, %9, %1"
+                                     : "=&v"(cs[0]), "=&v"(cs[1]), "=&s"(keep)
+                                     : "s"(ks4c[0]), "s"(ks4c[1]), "s"(ks4c[2]), "s"(ks4c[3]), "v"(qsc), "s"(0xFFFFFFFF00000000ull), "v"(sm26));
+                    } else {
+                        cs[0] = sm26 * (qsc * ksc[0][0]);
+                        cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
+                    }
                     // V fragments of tile t-1, one 32-channel tile at a time (two register sets, alternating)
                     v4i vfa[4], vfb[4];
                     auto read_v = [&](int dt, v4i (&vf)[4]) {
@@ -1470,11 +1509,16 @@ sage_attn_kernel(const AttnParams p_arg)
                         qk_next(1, 1); grp(15);
                     }
                     A_FENCE();
-                    float ksc_next[NH][2];
-                    load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
+                    if constexpr (KTHREAD && SAGE_KSEL) {
+                        const long tb = (long)((it + 1) >> p.ks_shift) * ks_tstride;      // (scalar loads, consumed at the next top; tile it + 1 exists: two whole tiles follow the loop)
+                        ks4c[0] = ks_c[tb]; ks4c[1] = ks_c[tb + 1]; ks4c[2] = ks_c[tb + 2]; ks4c[3] = ks_c[tb + 3];
+                    } else {
+                        float ksc_next[NH][2];
+                        load_kscales(it + 1, ksc_next);          // scalar load, consumed at the next top (behind the drained lgkmcnt)
+                        ksc[0][0] = ksc_next[0][0];
+                        ksc[0][1] = ksc_next[0][1];
+                    }
                     l_run = l_run * alpha + (rs0 + rs1);
-                    ksc[0][0] = ksc_next[0][0];
-                    ksc[0][1] = ksc_next[0][1];
                     alpha_p = alpha;
                     moved_p = moved;
                     it++;
@@ -1522,6 +1566,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     }
 #undef SAGE_RENAME
                 }
+                if constexpr (KTHREAD && SAGE_KSEL) { ksc[0][0] = g ? ks4c[2] : ks4c[0]; ksc[0][1] = g ? ks4c[3] : ks4c[1]; }
                 // drain: PV of the last pipelined tile (its V is in slot (cur + 2) % 3); V(it+1) is requested so that the general
                 // iteration finds tile it+1 "in flight" as a whole; then tile `it` must be complete and every wave past its reads
                 rescale();
