@@ -1054,7 +1054,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     A_FENCE();
 
                     // ---- exponentials / row sum / fp8 pack in 16 groups of two scores ----
-                    float rs0, rs1;                  // partial row sums: defined by the first group (grp(0) / g4b(0))
+                    float rs0, rs1;                  // partial row sums: defined by the first group (grp(0) / g4c(0))
                     auto grp = [&](int h) {          // scores 2h, 2h+1 of the lane's 32, in PV operand order: one statement =
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
@@ -1096,53 +1096,54 @@ sage_attn_kernel(const AttnParams p_arg)
                         const v4u b = *reinterpret_cast<const v4u *>(vr + swz_chunk<64>(drow, 2 * g + 1) * 16);
                         vf[dt] = v8i{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
                     };
-                    // D = 128: four scores per statement (four independent chains instead of two), in two halves so that an MFMA
-                    // can sit between the exponentials and the adds
-                    float u0, u1, u2, u3;
-                    auto g4a = [&](int w) {
+                    // D = 128: four scores per statement (four independent chains instead of two), in three parts -- scale (bias add + FMA), the
+                    // exponentials, row sum + fp8 pack -- so that every MFMA sits directly in front of a group's four exponentials: the
+                    // quarter-rate instructions overlap a running MFMA best (tools/microbench/ubench5), the next group's scale part follows
+                    // them, then this group's sums and packs (two sets of temporaries).  Against MFMAs in front of the scale parts:
+                    // +0.6 % at N = 32k, +1.2 % at C3 non-causal, bit-identical (profiles/r6_run_i_loop_trim_ab.txt).
+                    float ua[4], ub[4];
+                    auto g4s = [&](int w, float (&u)[4]) {
                         const int sb = w >> 2, i0 = 4 * (w & 3);
-#define SAGE_G4A(SCALE4)                                                                                                                        \
-                        asm volatile(SCALE4 A_EXP_ " %0, %0\n\t" A_EXP_ " %1, %1\n\t" A_EXP_ " %2, %2\n\t" A_EXP_ " %3, %3"                        \
-                                     : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)                                                                 \
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1))
                         if constexpr (SFOLD)
-                            SAGE_G4A(SAGE_SCALE2_FOLD("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2_FOLD("%2", "%3", "%6", "%7", "%9", "%9", "%11"));
+                            asm volatile(SAGE_SCALE2_FOLD("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2_FOLD("%2", "%3", "%6", "%7", "%9", "%9", "%11")
+                                         : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
                         else
-                            SAGE_G4A("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
-                                     "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
-                                     "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
-                                     "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11\n\t");
-#undef SAGE_G4A
+                            asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
+                                         "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
+                                         "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
+                                         "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11"
+                                         : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
                     };
-                    auto g4b = [&](int w) {
-                        if (w == 0)                  // (defines the partial row sums: 0 + u0 + u2 is u0 + u2)
+                    auto g4e = [&](float (&u)[4]) {
+                        asm volatile(A_EXP_ " %0, %0\n\t" A_EXP_ " %1, %1\n\t" A_EXP_ " %2, %2\n\t" A_EXP_ " %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
+                    };
+                    auto g4c = [&](int w, float (&u)[4]) {
+                        if (w == 0)
                             asm volatile("v_add_f32 %0, %3, %5\n\tv_add_f32 %1, %4, %6\n\t"
                                          "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
-                                         : "=&v"(rs0), "=&v"(rs1), "+v"(pc[w])
-                                         : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+                                         : "=&v"(rs0), "=&v"(rs1), "+v"(pc[w]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
                         else
-                        asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
-                                     "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
-                                     : "+v"(rs0), "+v"(rs1), "+v"(pc[w])
-                                     : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+                            asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %0, %0, %5\n\tv_add_f32 %1, %1, %6\n\t"
+                                         "v_cvt_pk_fp8_f32 %2, %3, %4\n\tv_cvt_pk_fp8_f32 %2, %5, %6 op_sel:[0,0,1]"
+                                         : "+v"(rs0), "+v"(rs1), "+v"(pc[w]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
                     };
                     if constexpr (C::DT == 4) {
-                        A_PV(o[2], vf[2], pp);
-                        g4a(0); g4b(0);
-                        A_PV(o[3], vf[3], pp);
-                        g4a(1); g4b(1);
-                        qk_next(0, 0); g4a(2);
-                        qk_next(0, 1); g4b(2); g4a(3);
-                        qk_next(0, 2); g4b(3);
-                        qk_next(0, 3); g4a(4);
+                        g4s(0, ua);
+                        A_PV(o[2], vf[2], pp);   g4e(ua); g4s(1, ub); g4c(0, ua);
+                        A_PV(o[3], vf[3], pp);   g4e(ub); g4s(2, ua); g4c(1, ub);
+                        qk_next(0, 0);           g4e(ua); g4s(3, ub); g4c(2, ua);
+                        qk_next(0, 1);           g4e(ub); g4s(4, ua); g4c(3, ub);
+                        qk_next(0, 2);           g4e(ua);
                         A_FENCE(); read_v(0); read_v(1); A_FENCE();
-                        g4b(4);
-                        qk_next(1, 0); g4a(5);
-                        qk_next(1, 1); g4b(5); g4a(6);
-                        qk_next(1, 2); g4b(6);
+                        g4s(5, ub); g4c(4, ua);
+                        qk_next(0, 3);           g4e(ub); g4s(6, ua); g4c(5, ub);
+                        qk_next(1, 0);           g4e(ua); g4s(7, ub); g4c(6, ua);
+                        qk_next(1, 1);           g4e(ub);
+                        qk_next(1, 2);           g4c(7, ub);
                         qk_next(1, 3);
                         A_FENCE(); read_v(2); read_v(3); A_FENCE();
-                        g4a(7); g4b(7);
                     } else {                         // D = 64: two PV MFMAs (dealt above), four QK^T MFMAs
                         grp(0); grp(1); grp(2); grp(3);
                         qk_next(0, 0); grp(4); grp(5); grp(6);
@@ -1463,33 +1464,69 @@ sage_attn_kernel(const AttnParams p_arg)
                             else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
                         }
                     };
+                    // D = 128: four scores per statement in three parts (scale / exponentials / pack + row sum), as in the FP8 loop: three MFMAs
+                    // per group, the first directly in front of the group's exponentials, and no nop between exponential and pack.  16 PV +
+                    // 8 QK^T MFMAs (32 cycles each); two 32-channel tiles are in flight and their MFMAs alternate, so consecutive MFMAs never share
+                    // an accumulator (a dependent MFMA issued behind other instructions waits for the full write-back).  Against round 5's
+                    // two-score groups with the MFMAs in front of them: C2 +2.5 ... +3.9 %, Triton-named API +2 ... +3.7 %, C4 +2.1 / +2.2 %,
+                    // bit-identical (profiles/r6_run_i_loop_trim_ab.txt).
+                    [[maybe_unused]] float ua[4], ub[4];
+                    auto g4s = [&](int w, float (&u)[4]) {
+                        const int sb = w >> 2, i0 = 4 * (w & 3);
+                        asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
+                                     "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
+                                     "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
+                                     "v_fma_f32 %2, %2, %9, -%10\n\tv_fma_f32 %3, %3, %9, -%10"
+                                     : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0));
+                    };
+                    auto g4e = [&](float (&u)[4]) {
+                        asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
+                    };
+                    auto g4c = [&](int w, float (&u)[4]) {
+                        if constexpr (RSUM16) {
+                            if (w == 0)
+                                asm volatile("v_cvt_pk_f16_f32 %2, %4, %5\n\tv_cvt_pk_f16_f32 %3, %6, %7\n\t"
+                                             "v_fma_mix_f32 %0, %2, 1.0, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, 1.0, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                             "v_fma_mix_f32 %0, %3, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %3, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                             : "=&v"(rs0), "=&v"(rs1), "=&v"(pc[w >> 1][(2 * w) & 3]), "=&v"(pc[w >> 1][(2 * w + 1) & 3]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+                            else
+                                asm volatile("v_cvt_pk_f16_f32 %2, %4, %5\n\tv_cvt_pk_f16_f32 %3, %6, %7\n\t"
+                                             "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                             "v_fma_mix_f32 %0, %3, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %3, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                             : "+v"(rs0), "+v"(rs1), "=&v"(pc[w >> 1][(2 * w) & 3]), "=&v"(pc[w >> 1][(2 * w + 1) & 3]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+                        } else {
+                            if (w == 0)
+                                asm volatile("v_add_f32 %0, %4, %6\n\tv_add_f32 %1, %5, %7\n\t"
+                                             "v_cvt_pk_f16_f32 %2, %4, %5\n\tv_cvt_pk_f16_f32 %3, %6, %7"
+                                             : "=&v"(rs0), "=&v"(rs1), "=&v"(pc[w >> 1][(2 * w) & 3]), "=&v"(pc[w >> 1][(2 * w + 1) & 3]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+                            else
+                                asm volatile("v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\t"
+                                             "v_cvt_pk_f16_f32 %2, %4, %5\n\tv_cvt_pk_f16_f32 %3, %6, %7"
+                                             : "+v"(rs0), "+v"(rs1), "=&v"(pc[w >> 1][(2 * w) & 3]), "=&v"(pc[w >> 1][(2 * w + 1) & 3]) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+                        }
+                    };
                     if constexpr (C::DT == 4) {
-                        // 16 PV + 8 QK^T MFMAs (32 cycles each) against 16 VALU groups of 9: one or two MFMAs per group.
-                        // Two 32-channel tiles are in flight and their MFMAs alternate, so consecutive MFMAs never share an
-                        // accumulator (a dependent MFMA issued behind other instructions waits for the full write-back).
-                        pv4(0, vfa, 0); grp(0);
-                        pv4(1, vfb, 0); grp(1);
-                        pv4(0, vfa, 1); pv4(1, vfb, 1); grp(2);
-                        pv4(0, vfa, 2); grp(3);
-                        pv4(1, vfb, 2); grp(4);
+                        g4s(0, ua);
+                        pv4(0, vfa, 0); g4e(ua); pv4(1, vfb, 0); g4s(1, ub); pv4(0, vfa, 1); g4c(0, ua);
+                        pv4(1, vfb, 1); g4e(ub); pv4(0, vfa, 2); g4s(2, ua); pv4(1, vfb, 2); g4c(1, ub);
                         pv4(0, vfa, 3);
                         A_FENCE(); read_v(2, vfa); A_FENCE();
+                        g4e(ua);
                         pv4(1, vfb, 3);
                         A_FENCE(); read_v(3, vfb); A_FENCE();
-                        grp(5); grp(6);
-                        pv4(2, vfa, 0); grp(7);
-                        pv4(3, vfb, 0); grp(8);
-                        pv4(2, vfa, 1); pv4(3, vfb, 1); grp(9);
-                        pv4(2, vfa, 2); grp(10);
-                        pv4(3, vfb, 2);
+                        g4s(3, ub); pv4(2, vfa, 0); g4c(2, ua);
+                        pv4(3, vfb, 0); g4e(ub); pv4(2, vfa, 1); g4s(4, ua); pv4(3, vfb, 1); g4c(3, ub);
+                        pv4(2, vfa, 2); g4e(ua); pv4(3, vfb, 2); g4s(5, ub);
                         pv4(2, vfa, 3);
                         A_FENCE(); read_k(0, kfa); A_FENCE();
+                        g4c(4, ua);
                         pv4(3, vfb, 3);
                         A_FENCE(); read_k(1, kfb); A_FENCE();
-                        grp(11); grp(12);
-                        qk_next(0, 0); qk_next(1, 0); grp(13);
-                        qk_next(0, 1); qk_next(1, 1); grp(14);
-                        qk_next(0, 2); qk_next(1, 2); grp(15);
+                        g4e(ub); g4s(6, ua);
+                        qk_next(0, 0); g4c(5, ub);
+                        qk_next(1, 0); g4e(ua); qk_next(0, 1); g4s(7, ub); qk_next(1, 1); g4c(6, ua);
+                        qk_next(0, 2); g4e(ub); qk_next(1, 2); g4c(7, ub);
                         qk_next(0, 3); qk_next(1, 3);
                     } else {                         // D = 64: 8 PV + 4 QK^T MFMAs
                         pv4(0, vfa, 0); grp(0);
