@@ -48,7 +48,7 @@ else:
     fl = bench.flops(cfg)
 ref = None
 t = {tag: [] for tag in tags}
-for rnd in range(4):
+for rnd in range(int(os.environ.get("SAGE_AB_ROUNDS", "4"))):      # (more rounds: differences below 1 %)
     for tag in tags:
         _cabi._lib = libs[tag]
         for _ in range(3):
