@@ -53,6 +53,9 @@
 #ifndef SAGE_ABL             // timing ablations of the FP8 pipelined loop (WRONG results; tools/build_variants.sh): 1 no O rescale, 2 no s_nop in
 #define SAGE_ABL 0           // front of the loop's MFMAs (since they were dropped: 2 = WITH them), 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
 #endif
+#ifndef SAGE_DIAG_PIPE       // causal FP8 D = 128: a work item's last two tiles through the pipelined body (1) or as general iterations (0: A/B)
+#define SAGE_DIAG_PIPE 1
+#endif
 #ifndef SAGE_KSEL            // pipelined loops, per-thread k scale groups: the lane halves' scale products under EXEC (1) or by select (0: A/B)
 #define SAGE_KSEL 1
 #endif
@@ -121,7 +124,7 @@ __device__ __forceinline__ v16i mfma_i8_first(v4i a, v4i b)
 }
 
 #if SAGE_ATTN_TRACE
-// (the stamps go to AttnParams::trace, a caller-owned buffer of 16 words per logical workgroup: 8 stamps, -, HW_ID, XCC_ID, blockIdx.x --
+// (the stamps go to AttnParams::trace, a caller-owned buffer of 16 words per logical workgroup: 8 stamps, -, HW_ID, XCC_ID, blockIdx.x, query block --
 //  SageLaunchAttr::trace / trace_wgs, read by trace builds only)
 #define SAGE_TSTAMP(i) do { if (wave == 0) { unsigned long long t_; \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ttrace[i] = (unsigned)t_; } } while (0)
@@ -894,6 +897,10 @@ sage_attn_kernel(const AttnParams p_arg)
             nd = nd > 0 ? nd : 0;
             n_steady = n_steady < nd ? n_steady : nd;
         }
+        // DIAG_PIPE (causal): when exactly two tiles follow the steady ones and both are whole, they run through the pipelined body as well (masked
+        // there) instead of as general iterations -- also when there is no steady tile at all (the first query block)
+        constexpr bool DIAG_PIPE = CAUSAL && SAGE_DIAG_PIPE && PV_FP8;
+        const bool diag_ok = DIAG_PIPE && (n_steady > 0 ? n_iters - n_steady == 2 : (n_iters == 2 && Lk >= 2 * KT));
 
         if constexpr (PV_FP8) {
             // ---- software-pipelined steady state -------------------------------------------------------------
@@ -931,7 +938,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #else
 #define A_EXP_ "v_exp_f32"
 #endif
-            if (it < n_steady) {
+            if (it < n_steady || diag_ok) {
                 v16i sA[2], sB[2];
                 {
                     const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
@@ -965,6 +972,8 @@ sage_attn_kernel(const AttnParams p_arg)
                 cs[0] = sm26 * (qsc * ksc[0][0]);
                 cs[1] = KTHREAD ? sm26 * (qsc * ksc[0][1]) : cs[0];
                 float alpha_p = 1.0f;            // rescale owed to O before the pending PV (kept out of the iteration's main block)
+                [[maybe_unused]] int cmy_row_d = 0;                      // DIAG_PIPE: the lane's row in the chunk's key coordinates, formed behind the loops
+                constexpr int kMaskedScore = (int)0xFF000000;           // bit pattern of a score behind the diagonal: below every INT32 score pattern, -1.7e38 as a float
                 auto rescale = [&]() {
                     if ((SAGE_ABL & 1) == 0 && __builtin_amdgcn_ballot_w64(alpha_p != 1.0f) != 0) {
 #pragma unroll
@@ -977,7 +986,12 @@ sage_attn_kernel(const AttnParams p_arg)
                 // (`slot` = the ring slot of tile `it`, a compile-time constant: the six bodies of the loop below are the six combinations of
                 //  ring slot and score-register set, so every LDS address of a body is a loop-invariant per-lane offset plus an immediate --
                 //  no per-tile address arithmetic on the VALU)
-                auto body = [&](auto slot, const int n, const int g, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {   // (n, g: the lane's row and half, see the remainder loop)
+                // `kind` 0: a whole tile of the steady state.  1 / 2 (DIAG_PIPE): the last two tiles of a causal work item in the same instruction order --
+                // scores behind the diagonal are replaced by kMaskedScore in front of the row maximum, nothing more is fetched (1: QK^T of the
+                // last tile still issued; 2: no next tile at all)
+                auto body = [&](auto slot, auto kind, const int n, const int g, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {   // (n, g: the lane's row and half, see the remainder loop)
+                    constexpr int KIND = decltype(kind)::value;
+                    constexpr bool HAS_DMA = KIND == 0, HAS_NEXT = KIND != 2, DIAG = KIND != 0;
                     rescale();
                     const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
                     const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
@@ -985,7 +999,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     if ((SAGE_ABL & 4) == 0) __builtin_amdgcn_s_barrier();
-                    {
+                    if constexpr (HAS_DMA) {
                         // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
                         // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
                         const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
@@ -1019,16 +1033,31 @@ sage_attn_kernel(const AttnParams p_arg)
                     // instructions per tile less than move + select + multiply; same multiplications in the same order: same bits)
                     float ksc_next[NH][2];
                     [[maybe_unused]] float ks4[4];
-                    if constexpr (KTHREAD && SAGE_KSEL) {
+                    if constexpr (!HAS_NEXT) {
+                    } else if constexpr (KTHREAD && SAGE_KSEL) {
                         const long tb = (long)((it + 1) >> p.ks_shift) * ks_tstride;      // (whole tiles only in this loop: it + 1 < ntk_all)
                         ks4[0] = ks_c[tb]; ks4[1] = ks_c[tb + 1]; ks4[2] = ks_c[tb + 2]; ks4[3] = ks_c[tb + 3];
                     } else load_kscales(it + 1, ksc_next);
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
+                    if constexpr (HAS_NEXT) {
 #pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                        for (int kk = 0; kk < C::KSTEPS; kk++) {
+                            kfa[kk] = *reinterpret_cast<const v4i *>(ksn + n * D + swz_chunk<D>(n, 2 * kk + g) * 16);
+                        }
                     }
                     A_FENCE();
+                    // the scale the score FMAs use: in a masked tile never below 2^-100, so that kMaskedScore * c is a large negative number even when
+                    // a q or k scale is zero (c < 2^-100 multiplies scores below 2^-5 into nothing against any m either way: same bits)
+                    float csx[2] = {cs[0], cs[1]};
+                    if constexpr (DIAG) {
+                        const int x = cmy_row_d - it * KT - 4 * g;        // the lane's last visible key of this tile, minus its half's offset
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
+                        csx[0] = fmaxf(cs[0], 0x1p-100f);
+                        csx[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : csx[0];
+                    }
                     int mx0 = INT_MIN, mx1 = INT_MIN;
 #pragma unroll
                     for (int u = 0; u < 2; u++)
@@ -1043,13 +1072,15 @@ sage_attn_kernel(const AttnParams p_arg)
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
                     // SFOLD: what the scale FMA subtracts is the row maximum plus the bias of the score's bit pattern in this tile's scale
-                    const float mb0 = SFOLD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new) : m_new;
-                    const float mb1 = (SFOLD && KTHREAD) ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
+                    const float mb0 = SFOLD ? __builtin_fmaf(__int_as_float(0x3E22F983), csx[0], m_new) : m_new;
+                    const float mb1 = (SFOLD && KTHREAD) ? __builtin_fmaf(__int_as_float(0x3E22F983), csx[1], m_new) : mb0;
                     if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp);
                     A_FENCE();
+                    if constexpr (HAS_NEXT) {
 #pragma unroll
-                    for (int kk = 0; kk < C::KSTEPS; kk++) {
-                        kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                        for (int kk = 0; kk < C::KSTEPS; kk++) {
+                            kfb[kk] = *reinterpret_cast<const v4i *>(ksn + (32 + n) * D + swz_chunk<D>(32 + n, 2 * kk + g) * 16);
+                        }
                     }
                     A_FENCE();
 
@@ -1059,7 +1090,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
-                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        const float ca = csx[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = csx[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
 #define SAGE_GRP(SCALE2, PACK)                                                                                                  \
                         asm volatile(SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")                                             \
                                      "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
@@ -1086,7 +1117,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     auto &qfr = qf;                  // (named in the generic body itself: a lambda nested in it does not capture through it otherwise)
                     auto qk_next = [&](int sb, int kk) {
-                        if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
+                        if constexpr (!HAS_NEXT) return;
+                        else if (kk == 0) A_QK0(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
                         else A_QK(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
                     };
                     auto read_v = [&](int dt) {      // V fragments of THIS tile for the next iteration's PV
@@ -1107,14 +1139,14 @@ sage_attn_kernel(const AttnParams p_arg)
                         if constexpr (SFOLD)
                             asm volatile(SAGE_SCALE2_FOLD("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2_FOLD("%2", "%3", "%6", "%7", "%9", "%9", "%11")
                                          : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0), "v"(mb1));
                         else
                             asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
                                          "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
                                          "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
                                          "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11"
                                          : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0), "v"(mb1));
                     };
                     auto g4e = [&](float (&u)[4]) {
                         asm volatile(A_EXP_ " %0, %0\n\t" A_EXP_ " %1, %1\n\t" A_EXP_ " %2, %2\n\t" A_EXP_ " %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
@@ -1155,7 +1187,8 @@ sage_attn_kernel(const AttnParams p_arg)
                         grp(13); grp(14); grp(15);
                     }
                     l_run = l_run * alpha + (rs0 + rs1);
-                    if constexpr (KTHREAD && SAGE_KSEL) {
+                    if constexpr (!HAS_NEXT) {
+                    } else if constexpr (KTHREAD && SAGE_KSEL) {
                         unsigned long long keep;
                         asm volatile("v_mul_f32 %0, %3, %7\n\tv_mul_f32 %1, %4, %7\n\t"
                                      "s_mov_b64 %2, exec\n\ts_mov_b64 exec, %8\n\t"
@@ -1181,8 +1214,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 #pragma nounroll
                     for (; n6 > 0; n6--) {
-                        body(I0{}, n, g, sA, sB, pA, pB); body(I1{}, n, g, sB, sA, pB, pA); body(I2{}, n, g, sA, sB, pA, pB);
-                        body(I0{}, n, g, sB, sA, pB, pA); body(I1{}, n, g, sA, sB, pA, pB); body(I2{}, n, g, sB, sA, pB, pA);
+                        body(I0{}, I0{}, n, g, sA, sB, pA, pB); body(I1{}, I0{}, n, g, sB, sA, pB, pA); body(I2{}, I0{}, n, g, sA, sB, pA, pB);
+                        body(I0{}, I0{}, n, g, sB, sA, pB, pA); body(I1{}, I0{}, n, g, sA, sB, pA, pB); body(I2{}, I0{}, n, g, sB, sA, pB, pA);
                     }
                     // (the remainder body's per-lane LDS offsets are derived behind the six-body loop from a lane index the compiler cannot see
                     //  through: formed in front of it they would stay live across it, next to that loop's own -- registers D = 64 does not have)
@@ -1191,10 +1224,22 @@ sage_attn_kernel(const AttnParams p_arg)
                     const int n_r = lane_r & 31, g_r = lane_r >> 5;
 #pragma nounroll
                     for (; r > 0; r--) {
-                        body(cur, n_r, g_r, sA, sB, pA, pB);
+                        body(cur, I0{}, n_r, g_r, sA, sB, pA, pB);
                         SAGE_RENAME_S();
                         pA = pB;
                         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                    }
+                    // Causal: the work item's last two tiles (whole tiles both when exactly two are left: n_steady <= Lk / 64 - 2) keep the pipeline's
+                    // order instead of draining it into two general iterations -- the scores of the first are in set A already, the last steady
+                    // body requested the second.  Same arithmetic per score as a general tile's (bias subtraction + FMA against the same m): same bits.
+                    if constexpr (DIAG_PIPE) {
+                        if (diag_ok) {
+                            cmy_row_d = row0 - kchunk0 + n_r;
+                            body(cur, I1{}, n_r, g_r, sA, sB, pA, pB);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            body(cur, I2{}, n_r, g_r, sB, sA, pB, pA);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
                     }
                 }
                 // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
@@ -1202,7 +1247,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 rescale();
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA);
-                load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
+                if (!DIAG_PIPE || it < n_iters) load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                 __builtin_amdgcn_s_barrier();
             }
@@ -1757,6 +1802,7 @@ sage_attn_kernel(const AttnParams p_arg)
         if (lane == 9) p.trace[16 * bid + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
         if (lane == 10) p.trace[16 * bid + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
         if (lane == 11) p.trace[16 * bid + 11] = blockIdx.x;
+        if (lane == 12) p.trace[16 * bid + 12] = (unsigned)qblk;
     }
 #endif
     } while (0);
