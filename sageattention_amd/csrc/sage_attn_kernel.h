@@ -899,8 +899,10 @@ sage_attn_kernel(const AttnParams p_arg)
         }
         // DIAG_PIPE (causal): when exactly two tiles follow the steady ones and both are whole, they run through the pipelined body as well (masked
         // there) instead of as general iterations -- also when there is no steady tile at all (the first query block)
-        constexpr bool DIAG_PIPE = CAUSAL && SAGE_DIAG_PIPE && PV_FP8;
-        const bool diag_ok = DIAG_PIPE && (n_steady > 0 ? n_iters - n_steady == 2 : (n_iters == 2 && Lk >= 2 * KT));
+        // (FP16 PV: only behind at least one steady tile -- its first body is a form of its own -- and at D = 128: the D = 64 instantiations spill
+        //  5-10 VGPRs under their three-waves limit with the two extra bodies)
+        constexpr bool DIAG_PIPE = CAUSAL && SAGE_DIAG_PIPE && (PV_FP8 || D == 128);
+        const bool diag_ok = DIAG_PIPE && (n_steady > 0 ? n_iters - n_steady == 2 : (PV_FP8 && n_iters == 2 && Lk >= 2 * KT));
 
         if constexpr (PV_FP8) {
             // ---- software-pipelined steady state -------------------------------------------------------------
@@ -1050,11 +1052,13 @@ sage_attn_kernel(const AttnParams p_arg)
                     // a q or k scale is zero (c < 2^-100 multiplies scores below 2^-5 into nothing against any m either way: same bits)
                     float csx[2] = {cs[0], cs[1]};
                     if constexpr (DIAG) {
-                        const int x = cmy_row_d - it * KT - 4 * g;        // the lane's last visible key of this tile, minus its half's offset
+                        if (crow0 < it * KT + KT - 1) {                   // (wave-uniform: a wave whose first row sees the whole tile has nothing to mask)
+                            const int x = cmy_row_d - it * KT - 4 * g;    // the lane's last visible key of this tile, minus its half's offset
 #pragma unroll
-                        for (int u = 0; u < 2; u++)
+                            for (int u = 0; u < 2; u++)
 #pragma unroll
-                            for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
+                                for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
+                        }
                         csx[0] = fmaxf(cs[0], 0x1p-100f);
                         csx[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : csx[0];
                     }
@@ -1342,7 +1346,13 @@ sage_attn_kernel(const AttnParams p_arg)
                 // (`slot` = the ring slot of tile `it`, a compile-time constant as in the FP8 loop: every LDS address of a body is a loop-invariant
                 //  per-lane offset plus an immediate.  `first`: the work item's first body has no previous tile -- P = 0 against the (finite) V
                 //  of the current slot instead of slot (cur + 2) % 3, which nothing has been written to yet)
-                auto body = [&](auto slot, auto first, v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
+                //  `kind` 0: a steady tile; 1 / 2 (DIAG_PIPE): a causal work item's last two tiles, masked in front of the row maximum -- 1 requests only
+                //  V(t+1) and still issues the QK^T of the last tile, 2 fetches nothing and has no next tile)
+                [[maybe_unused]] int cmy_row_d = 0;
+                constexpr int kMaskedScore = (int)0xFF000000;           // (see the FP8 loop)
+                auto body = [&](auto slot, auto first, auto kind, v16i (&sc)[2], v16i (&sn)[2], v4i (&pp)[4], v4i (&pc)[4]) {
+                    constexpr int KIND = decltype(kind)::value;
+                    constexpr bool HAS_NEXT = KIND != 2, DIAG = KIND != 0;
                     rescale();
                     const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
                     const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
@@ -1352,7 +1362,20 @@ sage_attn_kernel(const AttnParams p_arg)
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    {   // LDS-DMA: K(t+2) -> K region of slot nn, V(t+1) -> V region of slot nxt (SGPR-base form, see the FP8 loop)
+                    if constexpr (KIND == 1) {       // V(t+1) alone (the drain's form)
+                        unsigned char *vsn = smem + nxt * C::STAGE_BYTES + C::K_TILE_BYTES;
+                        [[maybe_unused]] const unsigned char *vt = vbase + (VROWS ? 0L : (v_tile0 + (long)(it + 1) * v_tstride) * (long)C::V_IMG_BYTES);
+#pragma unroll
+                        for (int i = 0; i < VP / 4; i++) {
+                            const int pc_ = wave * (VP / 4) + i;
+                            if constexpr (VROWS)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + ((long)(it + 1) * BLKK + pc_ * RPP) * p.v_sl * 2 + voffr),
+                                                                 (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
+                            else
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc_ * 1024 + lane * 16),
+                                                                 (__attribute__((address_space(3))) void *)(vsn + pc_ * 1024), 16, 0, 0);
+                        }
+                    } else if constexpr (KIND == 0) {   // LDS-DMA: K(t+2) -> K region of slot nn, V(t+1) -> V region of slot nxt (SGPR-base form, see the FP8 loop)
                         const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
                         const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
                         const unsigned ldv = lds_base + nxt * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
@@ -1421,6 +1444,18 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     read_v(0, vfa);
                     A_FENCE();
+                    float csx[2] = {cs[0], cs[1]};   // (the score FMAs' scale, never below 2^-100 in a masked tile: see the FP8 loop)
+                    if constexpr (DIAG) {
+                        if (crow0 < it * KT + KT - 1) {
+                            const int x = cmy_row_d - it * KT - 4 * g;
+#pragma unroll
+                            for (int u = 0; u < 2; u++)
+#pragma unroll
+                                for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
+                        }
+                        csx[0] = fmaxf(cs[0], 0x1p-100f);
+                        csx[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : csx[0];
+                    }
                     // ---- row maximum of S(t) (plain code) ----
                     int mx0 = INT_MIN, mx1 = INT_MIN;
 #pragma unroll
@@ -1447,7 +1482,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         const int c = h >> 2, j0 = (h & 3) * 2;
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
-                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        const float ca = csx[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = csx[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
                         const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
                         if (h == 0) {
                             // the first group DEFINES the two partial row sums (0 + p is p: no zero initialisation; the un-rounded form needs no add)
@@ -1488,6 +1523,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     v4i kfa[C::KSTEPS], kfb[C::KSTEPS];
                     auto read_k = [&](int sb, v4i (&kf)[C::KSTEPS]) {
+                        if constexpr (!HAS_NEXT) return;
                         const int krow = sb * 32 + n;
 #pragma unroll
                         for (int kk = 0; kk < C::KSTEPS; kk++)
@@ -1501,7 +1537,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     auto &qfr = qf;                  // (named in the generic body itself: a lambda nested in it does not capture through it otherwise)
                     auto qk_next = [&](int sb, int kk) {
-                        if constexpr (NOPS) {
+                        if constexpr (!HAS_NEXT) return;
+                        else if constexpr (NOPS) {
                             if (kk == 0) A_QK0N(sn[sb], (sb == 0 ? kfa[0] : kfb[0]), qfr[0]);
                             else A_QKN(sn[sb], (sb == 0 ? kfa[kk] : kfb[kk]), qfr[kk]);
                         } else {
@@ -1523,7 +1560,7 @@ sage_attn_kernel(const AttnParams p_arg)
                                      "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
                                      "v_fma_f32 %2, %2, %9, -%10\n\tv_fma_f32 %3, %3, %9, -%10"
                                      : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0));
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0));
                     };
                     auto g4e = [&](float (&u)[4]) {
                         asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
@@ -1591,7 +1628,8 @@ sage_attn_kernel(const AttnParams p_arg)
                         qk_next(1, 1); grp(15);
                     }
                     A_FENCE();
-                    if constexpr (KTHREAD && SAGE_KSEL) {
+                    if constexpr (!HAS_NEXT) {
+                    } else if constexpr (KTHREAD && SAGE_KSEL) {
                         const long tb = (long)((it + 1) >> p.ks_shift) * ks_tstride;      // (scalar loads, consumed at the next top; tile it + 1 exists: two whole tiles follow the loop)
                         ks4c[0] = ks_c[tb]; ks4c[1] = ks_c[tb + 1]; ks4c[2] = ks_c[tb + 2]; ks4c[3] = ks_c[tb + 3];
                     } else {
@@ -1614,35 +1652,45 @@ sage_attn_kernel(const AttnParams p_arg)
                     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
                     if constexpr (SIX_BODIES) {
                         const int left = n_steady - it - 1;
-                        body(I0{}, std::true_type{}, sA, sB, pA, pB);
+                        body(I0{}, std::true_type{}, I0{}, sA, sB, pA, pB);
                         SAGE_RENAME();
                         cur = 1;
                         int n6 = left / 6, r = left - 6 * n6;
 #pragma nounroll
                         for (; n6 > 0; n6--) {
-                            body(I1{}, std::false_type{}, sA, sB, pA, pB); body(I2{}, std::false_type{}, sB, sA, pB, pA); body(I0{}, std::false_type{}, sA, sB, pA, pB);
-                            body(I1{}, std::false_type{}, sB, sA, pB, pA); body(I2{}, std::false_type{}, sA, sB, pA, pB); body(I0{}, std::false_type{}, sB, sA, pB, pA);
+                            body(I1{}, std::false_type{}, I0{}, sA, sB, pA, pB); body(I2{}, std::false_type{}, I0{}, sB, sA, pB, pA); body(I0{}, std::false_type{}, I0{}, sA, sB, pA, pB);
+                            body(I1{}, std::false_type{}, I0{}, sB, sA, pB, pA); body(I2{}, std::false_type{}, I0{}, sA, sB, pA, pB); body(I0{}, std::false_type{}, I0{}, sB, sA, pB, pA);
                         }
 #pragma nounroll
                         for (; r > 0; r--) {
-                            body(cur, std::false_type{}, sA, sB, pA, pB);
+                            body(cur, std::false_type{}, I0{}, sA, sB, pA, pB);
                             SAGE_RENAME();
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
                     } else {            // (D = 64 FP16 PV: the non-causal forms have no registers to spare under the three-waves limit for six bodies -- the run-time-slot body twice)
                         bool first_rt = true;
                         if ((n_steady - it) & 1) {           // odd count: one tile first, renamed (once per workgroup)
-                            body(cur, first_rt, sA, sB, pA, pB);
+                            body(cur, first_rt, I0{}, sA, sB, pA, pB);
                             first_rt = false;
                             SAGE_RENAME();
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
 #pragma nounroll
                         while (it < n_steady) {
-                            body(cur, first_rt, sA, sB, pA, pB);
+                            body(cur, first_rt, I0{}, sA, sB, pA, pB);
                             first_rt = false;
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                            body(cur, std::false_type{}, sB, sA, pB, pA);
+                            body(cur, std::false_type{}, I0{}, sB, sA, pB, pA);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+                    }
+                    // Causal: the last two tiles keep the pipeline's order (see the FP8 loop); scores of the first in set A, K of the second requested
+                    if constexpr (DIAG_PIPE) {
+                        if (diag_ok) {
+                            cmy_row_d = crow0 + n;
+                            body(cur, std::false_type{}, I1{}, sA, sB, pA, pB);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            body(cur, std::false_type{}, I2{}, sB, sA, pB, pA);
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
                     }
@@ -1665,6 +1713,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     // one head differing between two identical calls, once in a few hundred launches).
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                    if (!(DIAG_PIPE && diag_ok))         // (behind the diagonal bodies nothing is left to request)
 #pragma unroll
                     for (int i = 0; i < VP / 4; i++) {
                         const int pc_ = wave * (VP / 4) + i;
