@@ -56,6 +56,9 @@
 #ifndef SAGE_DIAG_PIPE       // causal FP8 D = 128: a work item's last two tiles through the pipelined body (1) or as general iterations (0: A/B)
 #define SAGE_DIAG_PIPE 1
 #endif
+#ifndef SAGE_TAIL_PIPE       // non-causal FP8: the last two whole tiles (+ a ragged one behind them) through the pipelined body (1) or as general iterations (0: A/B)
+#define SAGE_TAIL_PIPE 1
+#endif
 #ifndef SAGE_KSEL            // pipelined loops, per-thread k scale groups: the lane halves' scale products under EXEC (1) or by select (0: A/B)
 #define SAGE_KSEL 1
 #endif
@@ -252,10 +255,10 @@ sage_attn_kernel(const AttnParams p_arg)
     // (the same for everything derived from the thread index: hoisted out of the loop, the prologue's and the epilogue's per-lane
     //  offsets would stay live through the key loop -- 13-32 VGPRs spilled in every instantiation)
     int lane_v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if constexpr (PERS_OK) asm volatile("" : "+v"(lane_v));
+    if constexpr (PERS_OK) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_v));     // (per item: the builtin's value is hoisted out of the loop and lives through it)
     const int lane = lane_v;
     const int wave = wave_s;
-    const int tid = wave * 64 + lane;
+    [[maybe_unused]] const int tid = wave * 64 + lane;
     int n = lane & 31;            // query row inside the wave's 32-row tile
     int g = lane >> 5;            // k-group (operand half)
     SAGE_TSTAMP(0);
@@ -469,9 +472,9 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                 for (int i = 0; i < VP / 4; i++) {
                     const int pc = wave * (VP / 4) + i;
-                    int tok = tv * BLKK + pc * RPP + lane / CPRV;
+                    int tok = tv * BLKK + pc * RPP + lane_g / CPRV;
                     tok = tok < Lk ? tok : Lk - 1;
-                    const int row = pc * RPP + lane / CPRV, phys = lane % CPRV;
+                    const int row = pc * RPP + lane_g / CPRV, phys = lane_g % CPRV;
                     const int logical = D == 128 ? (phys ^ ((row & 3) << 2)) : phys;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + (long)tok * p.v_sl * 2 + logical * 16),
                                                      (__attribute__((address_space(3))) void *)(vs + hh * C::V_IMG_BYTES + pc * 1024), 16, 0, 0);
@@ -481,7 +484,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
             for (int i = 0; i < VP / 4; i++) {
                 const int pc = wave * (VP / 4) + i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc * 1024 + lane * 16),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vt + pc * 1024 + lane_g * 16),
                                                  (__attribute__((address_space(3))) void *)(vs + hh * C::V_IMG_BYTES + pc * 1024), 16, 0, 0);
             }
             }
@@ -903,6 +906,10 @@ sage_attn_kernel(const AttnParams p_arg)
         //  5-10 VGPRs under their three-waves limit with the two extra bodies)
         constexpr bool DIAG_PIPE = CAUSAL && SAGE_DIAG_PIPE && (PV_FP8 || D == 128);
         const bool diag_ok = DIAG_PIPE && (n_steady > 0 ? n_iters - n_steady == 2 : (PV_FP8 && n_iters == 2 && Lk >= 2 * KT));
+        // TAIL_PIPE (non-causal FP8 PV): the two whole tiles the steady loop leaves (it looks two tiles ahead) and a ragged last one behind them take the
+        // pipelined body as well -- keys past Lk masked like keys behind the diagonal, the ragged tile requested in the general (clamped) form
+        constexpr bool TAIL_PIPE = !CAUSAL && SAGE_TAIL_PIPE && PV_FP8;
+        const bool tail_ok = TAIL_PIPE && n_steady >= 0 && n_steady == Lk / KT - 2 && n_iters - n_steady <= (SAGE_TAIL_PIPE == 2 ? 2 : 3);
 
         if constexpr (PV_FP8) {
             // ---- software-pipelined steady state -------------------------------------------------------------
@@ -940,7 +947,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #else
 #define A_EXP_ "v_exp_f32"
 #endif
-            if (it < n_steady || diag_ok) {
+            if (it < n_steady || diag_ok || tail_ok) {
                 v16i sA[2], sB[2];
                 {
                     const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
@@ -993,7 +1000,7 @@ sage_attn_kernel(const AttnParams p_arg)
                 // last tile still issued; 2: no next tile at all)
                 auto body = [&](auto slot, auto kind, const int n, const int g, v16i (&sc)[2], v16i (&sn)[2], v8i &pp, v8i &pc) {   // (n, g: the lane's row and half, see the remainder loop)
                     constexpr int KIND = decltype(kind)::value;
-                    constexpr bool HAS_DMA = KIND == 0, HAS_NEXT = KIND != 2, DIAG = KIND != 0;
+                    constexpr bool HAS_DMA = KIND == 0 || KIND == 3, HAS_NEXT = KIND != 2, DIAG = KIND == 1 || KIND == 2;       // (3, TAIL_PIPE: the tile requested is ragged)
                     rescale();
                     const int CUR = slot;            // (std::integral_constant in the six-body loop: folds; an int in the remainder loop)
                     const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
@@ -1004,25 +1011,36 @@ sage_attn_kernel(const AttnParams p_arg)
                     if constexpr (HAS_DMA) {
                         // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
                         // inst_offset advances the global and the LDS address together, so piece 1 reuses piece 0's M0.
-                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl;
+                        // (KIND 3: piece 1's clamped offset minus its inst_offset can be negative, and the VGPR offset of the SGPR-base form is unsigned:
+                        //  base 1 KiB down, offsets 1 KiB up)
+                        const unsigned char *ktp = kbase + (long)(it + 2) * KT * p.k_sl - (KIND == 3 ? 1024 : 0);
                         const unsigned char *vtp = vbase + (v_tile0 + (long)(it + 2) * v_tstride) * (long)C::V_IMG_BYTES + wave * (VP / 4) * 1024;
                         const unsigned ldk = lds_base + nn * C::STAGE_BYTES + wave * (KP / 4) * 1024;
                         const unsigned ldv = lds_base + nn * C::STAGE_BYTES + C::K_TILE_BYTES + wave * (VP / 4) * 1024;
                         unsigned keep;
+                        // (KIND 3: tile it + 2 is the ragged one -- its rows past Lk are read from the last row there is, as issue_loads does; the V image
+                        //  is whole, zero-padded)
+                        unsigned k0 = koff[0], k1m = koff1m;
+                        if constexpr (KIND == 3) {
+                            const int rmax = Lk - 1 - (it + 2) * KT, l64 = g * 32 + n;
+                            const int r0 = ((wave * (KP / 4)) * 64 + l64) / CPR, r1 = ((wave * (KP / 4) + 1) * 64 + l64) / CPR;
+                            k0 = k0 + 1024u - (unsigned)((r0 > rmax ? r0 - rmax : 0) * (int)p.k_sl);
+                            if constexpr (KP / 4 == 2) k1m = k1m + 1024u - (unsigned)((r1 > rmax ? r1 - rmax : 0) * (int)p.k_sl);
+                        }
                         if constexpr (KP / 4 == 2)
                             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
                                          "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
                                          "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
                                          "global_load_lds_dwordx4 %7, %4\n\tglobal_load_lds_dwordx4 %7, %4 offset:1024\n\t"
                                          "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "v"(koff1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                                         : "=&s"(keep) : "v"(k0), "v"(k1m), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
                         else
                             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
                                          "global_load_lds_dwordx4 %1, %2\n\t"
                                          "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
                                          "global_load_lds_dwordx4 %6, %3\n\t"
                                          "s_mov_b32 m0, %0"
-                                         : "=&s"(keep) : "v"(koff[0]), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
+                                         : "=&s"(keep) : "v"(k0), "s"(ktp), "s"(vtp), "s"(ldk), "s"(ldv), "v"(voff16) : "memory");
                     }
 
                     // ---- PV(t-1) MFMAs 0, 1; row maximum of S(t) (plain code: it only has to finish before the first exponential) ----
@@ -1048,19 +1066,19 @@ sage_attn_kernel(const AttnParams p_arg)
                         }
                     }
                     A_FENCE();
-                    // the scale the score FMAs use: in a masked tile never below 2^-100, so that kMaskedScore * c is a large negative number even when
-                    // a q or k scale is zero (c < 2^-100 multiplies scores below 2^-5 into nothing against any m either way: same bits)
-                    float csx[2] = {cs[0], cs[1]};
+                    // (the tile's score scale in a masked tile: never below 2^-100, so that kMaskedScore * c is a large negative number even when a
+                    //  q or k scale is zero -- c < 2^-100 multiplies scores below 2^-5 into nothing against any m and any offset either way: same bits)
                     if constexpr (DIAG) {
-                        if (crow0 < it * KT + KT - 1) {                   // (wave-uniform: a wave whose first row sees the whole tile has nothing to mask)
-                            const int x = cmy_row_d - it * KT - 4 * g;    // the lane's last visible key of this tile, minus its half's offset
+                        if (CAUSAL ? (crow0 < it * KT + KT - 1) : (Lk < it * KT + KT)) {     // (wave-uniform: a wave whose first row sees the whole tile has nothing to mask)
+                            // the lane's last visible key of this tile (causal: its row; otherwise the last key there is), minus its half's offset
+                            const int x = (CAUSAL ? cmy_row_d : Lk - 1) - it * KT - 4 * g;
 #pragma unroll
                             for (int u = 0; u < 2; u++)
 #pragma unroll
                                 for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
                         }
-                        csx[0] = fmaxf(cs[0], 0x1p-100f);
-                        csx[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : csx[0];
+                        cs[0] = fmaxf(cs[0], 0x1p-100f);
+                        cs[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : cs[0];
                     }
                     int mx0 = INT_MIN, mx1 = INT_MIN;
 #pragma unroll
@@ -1076,8 +1094,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
                     // SFOLD: what the scale FMA subtracts is the row maximum plus the bias of the score's bit pattern in this tile's scale
-                    const float mb0 = SFOLD ? __builtin_fmaf(__int_as_float(0x3E22F983), csx[0], m_new) : m_new;
-                    const float mb1 = (SFOLD && KTHREAD) ? __builtin_fmaf(__int_as_float(0x3E22F983), csx[1], m_new) : mb0;
+                    const float mb0 = SFOLD ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[0], m_new) : m_new;
+                    const float mb1 = (SFOLD && KTHREAD) ? __builtin_fmaf(__int_as_float(0x3E22F983), cs[1], m_new) : mb0;
                     if constexpr (C::DT > 1) A_PV(o[1], vf[1], pp);
                     A_FENCE();
                     if constexpr (HAS_NEXT) {
@@ -1094,7 +1112,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         const int c = h >> 2, j0 = (h & 3) * 2;                  // 2 x (bias sub, scale fma, exp2, row-sum add) + fp8 pack
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
-                        const float ca = csx[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = csx[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
 #define SAGE_GRP(SCALE2, PACK)                                                                                                  \
                         asm volatile(SCALE2("%2", "%3", "%5", "%6", "%7", "%8", "%9")                                             \
                                      "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
@@ -1143,14 +1161,14 @@ sage_attn_kernel(const AttnParams p_arg)
                         if constexpr (SFOLD)
                             asm volatile(SAGE_SCALE2_FOLD("%0", "%1", "%4", "%5", "%8", "%8", "%10") SAGE_SCALE2_FOLD("%2", "%3", "%6", "%7", "%9", "%9", "%11")
                                          : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0), "v"(mb1));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
                         else
                             asm volatile("v_add_f32 %0, 0xbe22f983, %4\n\tv_add_f32 %1, 0xbe22f983, %5\n\t"
                                          "v_add_f32 %2, 0xbe22f983, %6\n\tv_add_f32 %3, 0xbe22f983, %7\n\t"
                                          "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
                                          "v_fma_f32 %2, %2, %9, -%11\n\tv_fma_f32 %3, %3, %9, -%11"
                                          : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0), "v"(mb1));
+                                         : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0), "v"(mb1));
                     };
                     auto g4e = [&](float (&u)[4]) {
                         asm volatile(A_EXP_ " %0, %0\n\t" A_EXP_ " %1, %1\n\t" A_EXP_ " %2, %2\n\t" A_EXP_ " %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
@@ -1223,8 +1241,8 @@ sage_attn_kernel(const AttnParams p_arg)
                     }
                     // (the remainder body's per-lane LDS offsets are derived behind the six-body loop from a lane index the compiler cannot see
                     //  through: formed in front of it they would stay live across it, next to that loop's own -- registers D = 64 does not have)
-                    int lane_r = lane;
-                    asm volatile("" : "+v"(lane_r));
+                    int lane_r;                      // (v_mbcnt again rather than a copy of `lane`: nothing of the thread index has to live through the loop)
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_r));
                     const int n_r = lane_r & 31, g_r = lane_r >> 5;
 #pragma nounroll
                     for (; r > 0; r--) {
@@ -1236,22 +1254,42 @@ sage_attn_kernel(const AttnParams p_arg)
                     // Causal: the work item's last two tiles (whole tiles both when exactly two are left: n_steady <= Lk / 64 - 2) keep the pipeline's
                     // order instead of draining it into two general iterations -- the scores of the first are in set A already, the last steady
                     // body requested the second.  Same arithmetic per score as a general tile's (bias subtraction + FMA against the same m): same bits.
+                    // (the last bodies' per-lane offsets from a lane index of their own: shared with the remainder loop's they stay live across it)
+                    int lane_t;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+                    const int n_t = lane_t & 31, g_t = lane_t >> 5;
                     if constexpr (DIAG_PIPE) {
                         if (diag_ok) {
-                            cmy_row_d = row0 - kchunk0 + n_r;
-                            body(cur, I1{}, n_r, g_r, sA, sB, pA, pB);
+                            cmy_row_d = row0 - kchunk0 + n_t;
+                            body(cur, I1{}, n_t, g_t, sA, sB, pA, pB);
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-                            body(cur, I2{}, n_r, g_r, sB, sA, pB, pA);
+                            body(cur, I2{}, n_t, g_t, sB, sA, pB, pA);
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
                     }
+                    if constexpr (TAIL_PIPE) {
+                        if (tail_ok) {
+                            if (SAGE_TAIL_PIPE != 2 && n_iters - it == 3) {           // a ragged tile behind the two whole ones: this body requests it
+                                body(cur, std::integral_constant<int, 3>{}, n_t, g_t, sA, sB, pA, pB);
+                                SAGE_RENAME_S();
+                                pA = pB;
+                                cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            }
+                            body(cur, I1{}, n_t, g_t, sA, sB, pA, pB);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                            body(cur, I2{}, n_t, g_t, sB, sA, pB, pA);
+                            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+                        }
+                    }
+                    n = n_t;                         // (what follows -- the drain's k scales, the general tiles -- reads the lane's row and half formed behind the loop)
+                    g = g_t;
                 }
                 // drain: PV of the last pipelined tile; then every wave must be past its V reads before the general
                 // iteration issues the LDS-DMA of tile it+2 into that slot
                 rescale();
 #pragma unroll
                 for (int dt = 0; dt < C::DT; dt++) A_PV(o[dt], vf[dt], pA);
-                if (!DIAG_PIPE || it < n_iters) load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
+                if (it < n_iters) load_kscales(it, ksc);           // (the loop carried the products, not the k scales: the general iterations start from these)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(sA[0]), "+v"(sA[1])::"memory");   // (sA as operand: its readers stay below)
                 __builtin_amdgcn_s_barrier();
             }
@@ -1444,8 +1482,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     read_v(0, vfa);
                     A_FENCE();
-                    float csx[2] = {cs[0], cs[1]};   // (the score FMAs' scale, never below 2^-100 in a masked tile: see the FP8 loop)
-                    if constexpr (DIAG) {
+                    if constexpr (DIAG) {                // (the score scale of a masked tile never below 2^-100: see the FP8 loop)
                         if (crow0 < it * KT + KT - 1) {
                             const int x = cmy_row_d - it * KT - 4 * g;
 #pragma unroll
@@ -1453,8 +1490,8 @@ sage_attn_kernel(const AttnParams p_arg)
 #pragma unroll
                                 for (int i = 0; i < 16; i++) sc[u][i] = (u * 32 + 8 * (i >> 2) + (i & 3) <= x) ? sc[u][i] : kMaskedScore;
                         }
-                        csx[0] = fmaxf(cs[0], 0x1p-100f);
-                        csx[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : csx[0];
+                        cs[0] = fmaxf(cs[0], 0x1p-100f);
+                        cs[1] = KTHREAD ? fmaxf(cs[1], 0x1p-100f) : cs[0];
                     }
                     // ---- row maximum of S(t) (plain code) ----
                     int mx0 = INT_MIN, mx1 = INT_MIN;
@@ -1482,7 +1519,7 @@ sage_attn_kernel(const AttnParams p_arg)
                         const int c = h >> 2, j0 = (h & 3) * 2;
                         const int sb = c >> 1, i0 = (c & 1) * 8 + j0;
                         float t0, t1;
-                        const float ca = csx[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = csx[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
+                        const float ca = cs[(KTHREAD && (i0 & 2)) ? 1 : 0], cb = cs[(KTHREAD && ((i0 + 1) & 2)) ? 1 : 0];
                         const float mb = (KTHREAD && (i0 & 2)) ? mb1 : mb0;       // (i0 is even: both scores share the k scale)
                         if (h == 0) {
                             // the first group DEFINES the two partial row sums (0 + p is p: no zero initialisation; the un-rounded form needs no add)
@@ -1560,7 +1597,7 @@ sage_attn_kernel(const AttnParams p_arg)
                                      "v_fma_f32 %0, %0, %8, -%10\n\tv_fma_f32 %1, %1, %8, -%10\n\t"
                                      "v_fma_f32 %2, %2, %9, -%10\n\tv_fma_f32 %3, %3, %9, -%10"
                                      : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(csx[0]), "v"(csx[1]), "v"(mb0));
+                                     : "v"(sc[sb][i0]), "v"(sc[sb][i0 + 1]), "v"(sc[sb][i0 + 2]), "v"(sc[sb][i0 + 3]), "v"(cs[0]), "v"(cs[1]), "v"(mb0));
                     };
                     auto g4e = [&](float (&u)[4]) {
                         asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
@@ -1752,7 +1789,7 @@ sage_attn_kernel(const AttnParams p_arg)
         // the general iterations' and the epilogue's per-lane values (LDS offsets, the lane's row) are re-derived here from a lane index the
         // compiler cannot see through: formed before the pipelined loops they stay live across them, and the D = 64 instantiations, which
         // have no register to spare under their three-waves limit, spill them
-        asm volatile("" : "+v"(lane_g));
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_g));
         n = lane_g & 31;
         g = lane_g >> 5;
         my_row = row0 + n;
@@ -1765,7 +1802,7 @@ sage_attn_kernel(const AttnParams p_arg)
     SAGE_TSTAMP(5);
     // persistent launch: the next ticket is requested here, behind the last tile, and read after the output rows are on their way
     if (pers && !own_empty) {
-        if (tid == 0) next_k_v = __hip_atomic_fetch_add(kpl()->sched + 32 * my_queue(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && lane_g == 0) next_k_v = __hip_atomic_fetch_add(kpl()->sched + 32 * my_queue(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         have_next = true;
     }
 
@@ -1836,7 +1873,7 @@ sage_attn_kernel(const AttnParams p_arg)
         unsigned char *obase = reinterpret_cast<unsigned char *>(p.o) + 2 * o_off;
 #pragma unroll
         for (int pass = 0; pass < 32 / RPP; pass++) {
-            const int r = pass * RPP + lane / LPR, Q = lane % LPR;
+            const int r = pass * RPP + lane_g / LPR, Q = lane_g % LPR;
             const v4u val = *reinterpret_cast<const v4u *>(obuf + r * (D * 2) + (Q ^ (r & 7)) * 16);
             const int grow = row0 + r;
             if (grow < Lq) *reinterpret_cast<v4u *>(obase + 2 * ((long)grow * p.o_sl) + Q * 16) = val;

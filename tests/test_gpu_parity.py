@@ -1470,6 +1470,57 @@ def test_every_count_of_pipelined_tiles(oracle_mod, pv, D, ns):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
 
 
+@pytest.mark.parametrize("Lk", [128, 129, 160, 191, 192, 193, 200, 255, 256, 257, 320, 383, 449, 641, 704, 705])
+@pytest.mark.parametrize("D", [128, 64])
+def test_last_tiles_of_a_non_causal_fp8_call_through_the_pipelined_body(oracle_mod, D, Lk):
+    """Non-causal FP8 PV: the two whole tiles the steady loop leaves behind (it looks two tiles ahead) and a ragged last tile run the pipelined
+    body too since round 6 -- keys past Lk masked in front of the row maximum, the ragged tile requested with its rows clamped to the last key
+    (a negative per-lane offset there was a memory fault once: the VGPR offset of the SGPR-base LDS-DMA is unsigned).  Lk from two tiles up:
+    no steady tile at all, every remainder, ragged tails of 1 ... 63 keys; K is the last tensor allocated, so rows past its end are not ours."""
+    Lq, dt = 136, Lk & 1
+    q, k, v = rand_qkv(1, 2, 2, Lq, Lk, D, dt, seed=2000 + Lk, kbias=1.0)
+    km = util.bits(sq.channel_mean(k.to(DEV)))
+    for gran in ("per_thread", "per_warp"):
+        o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=False, pv="f8", qk_quant_gran=gran,
+                                                       return_lse=True, km=km, fp8_scores=SCORES)
+        qd, vd = q.to(DEV), v.to(DEV)
+        kd = k.to(DEV)
+        o, lse = sa.sageattn_qk_int8_pv_fp8_cuda(qd, kd, vd, is_causal=False, qk_quant_gran=gran, pv_accum_dtype="fp32+fp32", return_lse=True)
+        torch.cuda.synchronize()
+        got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max())
+        assert np.isfinite(got).all()
+        assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"D{D} Lk{Lk} {gran}: {err:.3e} vs {scale:.3e}"
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
+
+
+@pytest.mark.parametrize("L", [128, 192, 256, 320, 384, 512, 896])
+@pytest.mark.parametrize("pv,D", [("f16_two", 128), ("f16_single", 128), ("f8_two", 128), ("f8_two", 64)])
+def test_diagonal_tiles_of_a_causal_call_through_the_pipelined_body(oracle_mod, pv, D, L):
+    """Causal, whole 64-key tiles: a work item's last two tiles (the diagonal ones when Lq = Lk) take the pipelined body since round 6 -- scores
+    behind the diagonal replaced by a large negative pattern in front of the row maximum -- FP8 PV also in the first query block, which has
+    no steady tile in front of them.  L = 192 / 320: the last query block is half a block (general tiles there); Lq != Lk: the last two
+    tiles are not the diagonal ones for every block."""
+    dt = (L >> 6) & 1
+    fp8 = pv.startswith("f8")
+    for Lq, Lk in ((L, L), (L, L + 128), (L + 64, L)):
+        q, k, v = rand_qkv(1, 2, 1, Lq, Lk, D, dt, seed=3000 + L + Lq, kbias=1.0)
+        km = util.bits(sq.channel_mean(k.to(DEV)))
+        o_bits, lse_ref, _ = oracle_mod.sageattn_dense(util.bits(q), util.bits(k), util.bits(v), dt, is_causal=True, pv="f8" if fp8 else "f16",
+                                                       qk_quant_gran="per_thread", return_lse=True, km=km,
+                                                       warpq=16 if (pv == "f16_two" and D == 128) else 32, fp8_scores=SCORES)
+        fn = sa.sageattn_qk_int8_pv_fp8_cuda if fp8 else sa.sageattn_qk_int8_pv_fp16_cuda
+        o, lse = fn(q.to(DEV), k.to(DEV), v.to(DEV), is_causal=True, qk_quant_gran="per_thread", pv_accum_dtype=PV_ACCUM[pv], return_lse=True)
+        torch.cuda.synchronize()
+        got, ref = o.float().cpu().numpy(), util.f32(o_bits, dt)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max())
+        assert np.isfinite(got).all()
+        assert err <= 2e-3 * scale + util.out_ulp(scale, dt), f"{pv} D{D} Lq{Lq} Lk{Lk}: {err:.3e} vs {scale:.3e}"
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= (5e-3 if dt == 0 else 2e-2)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("SAGE_RANDOM_SEEDS", "100")))))
 def test_random_calls_of_the_other_entry_points_vs_oracle(oracle_mod, seed):
     """The seeded sweep above for the entry points it does not reach: the Triton-named API (per-block scales, Q quantised in the kernel),
