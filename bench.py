@@ -62,6 +62,7 @@ CONFIGS = {
     "h12": dict(B=1, H=12, Hkv=12, N=8192, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe B=1 H=12 N=8192 causal"),
     "d64f16": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp16", dtype="fp16", workload="probe D=64 FP16 PV B=2 H=32 N=8192 causal"),
     "n32k": dict(B=1, H=16, Hkv=16, N=32768, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe steady state B=1 H=16 N=32768 D=128 causal"),
+    "c2nc": dict(B=2, H=32, Hkv=32, N=4096, D=128, causal=False, pv="fp16", dtype="fp16", workload="probe C2 shape NON-causal (FP16 PV tails)"),
     "c2l": dict(B=1, H=16, Hkv=16, N=16384, D=128, causal=True, pv="fp16", dtype="fp16", workload="probe steady state FP16 PV B=1 H=16 N=16384 D=128 causal"),
     "d64f8": dict(B=2, H=32, Hkv=32, N=8192, D=64, causal=True, pv="fp8", dtype="bf16", workload="probe D=64 FP8 PV B=2 H=32 N=8192 causal"),
     "n1k": dict(B=2, H=32, Hkv=32, N=1024, D=128, causal=True, pv="fp8", dtype="bf16", workload="probe C3 shape at N=1024"),

@@ -908,8 +908,10 @@ sage_attn_kernel(const AttnParams p_arg)
         const bool diag_ok = DIAG_PIPE && (n_steady > 0 ? n_iters - n_steady == 2 : (PV_FP8 && n_iters == 2 && Lk >= 2 * KT));
         // TAIL_PIPE (non-causal FP8 PV): the two whole tiles the steady loop leaves (it looks two tiles ahead) and a ragged last one behind them take the
         // pipelined body as well -- keys past Lk masked like keys behind the diagonal, the ragged tile requested in the general (clamped) form
-        constexpr bool TAIL_PIPE = !CAUSAL && SAGE_TAIL_PIPE && PV_FP8;
-        const bool tail_ok = TAIL_PIPE && n_steady >= 0 && n_steady == Lk / KT - 2 && n_iters - n_steady <= (SAGE_TAIL_PIPE == 2 ? 2 : 3);
+        // (FP16 PV, D = 128: the two whole tiles of a call whose Lk is a multiple of 64, behind at least one steady tile -- kinds 1 and 2 as they are)
+        constexpr bool TAIL_PIPE = !CAUSAL && SAGE_TAIL_PIPE && (PV_FP8 || D == 128);
+        const bool tail_ok = TAIL_PIPE && n_steady == Lk / KT - 2 &&
+                             (PV_FP8 ? (n_steady >= 0 && n_iters - n_steady <= (SAGE_TAIL_PIPE == 2 ? 2 : 3)) : (n_steady > 0 && n_iters - n_steady == 2));
 
         if constexpr (PV_FP8) {
             // ---- software-pipelined steady state -------------------------------------------------------------
@@ -1333,7 +1335,7 @@ sage_attn_kernel(const AttnParams p_arg)
 #define A_QK0N(acc, a, b)   asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0x3e22f983" : "=&v"(acc) : "v"(a), "v"(b))
 #define A_QKN(acc, a, b)    asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define A_FENCE()          asm volatile("" ::: "memory")
-            if (it < n_steady) {
+            if (it < n_steady) {                 // (diag_ok / tail_ok need a steady tile here: n_steady > 0)
                 v16i sA[2], sB[2];
                 {
                     const unsigned char *ks0 = smem + cur * C::STAGE_BYTES;
@@ -1482,7 +1484,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     };
                     read_v(0, vfa);
                     A_FENCE();
-                    if constexpr (DIAG) {                // (the score scale of a masked tile never below 2^-100: see the FP8 loop)
+                    if constexpr (DIAG && CAUSAL) {      // (the score scale of a masked tile never below 2^-100: see the FP8 loop; non-causal: whole tiles only)
                         if (crow0 < it * KT + KT - 1) {
                             const int x = cmy_row_d - it * KT - 4 * g;
 #pragma unroll
@@ -1722,8 +1724,8 @@ sage_attn_kernel(const AttnParams p_arg)
                         }
                     }
                     // Causal: the last two tiles keep the pipeline's order (see the FP8 loop); scores of the first in set A, K of the second requested
-                    if constexpr (DIAG_PIPE) {
-                        if (diag_ok) {
+                    if constexpr (DIAG_PIPE || TAIL_PIPE) {
+                        if (diag_ok || tail_ok) {
                             cmy_row_d = crow0 + n;
                             body(cur, std::false_type{}, I1{}, sA, sB, pA, pB);
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
@@ -1750,7 +1752,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     // one head differing between two identical calls, once in a few hundred launches).
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    if (!(DIAG_PIPE && diag_ok))         // (behind the diagonal bodies nothing is left to request)
+                    if (!(diag_ok || tail_ok))           // (behind the last bodies nothing is left to request)
 #pragma unroll
                     for (int i = 0; i < VP / 4; i++) {
                         const int pc_ = wave * (VP / 4) + i;
