@@ -51,7 +51,7 @@
 // v_mfma_f32_32x32x64_f8f6f4; two-level requests accumulate P.V through the MFMA's FP32 C operand and rescale O only where a row maximum of
 // the wave moved; the ticket loop in the non-causal kernels and in the packed route's causal ones.
 #ifndef SAGE_ABL             // timing ablations of the FP8 pipelined loop (WRONG results; tools/build_variants.sh): 1 no O rescale, 2 no s_nop in
-#define SAGE_ABL 0           // front of the loop's MFMAs (since they were dropped: 2 = WITH them), 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead)
+#define SAGE_ABL 0           // front of the loop's MFMAs (since they were dropped: 2 = WITH them), 4 no per-tile barrier, 8 no row-maximum chain, 16 no exponentials (v_mov instead), 32 no wait for the next tile's LDS-DMA at the top of a body
 #endif
 #ifndef SAGE_DIAG_PIPE       // causal FP8 D = 128: a work item's last two tiles through the pipelined body (1) or as general iterations (0: A/B)
 #define SAGE_DIAG_PIPE 1
@@ -1008,7 +1008,7 @@ sage_attn_kernel(const AttnParams p_arg)
                     const int nxt = (CUR + 1 == NSTAGE) ? 0 : CUR + 1, nn = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
                     const unsigned char *vs = smem + CUR * C::STAGE_BYTES + C::K_TILE_BYTES;
                     const unsigned char *ksn = smem + nxt * C::STAGE_BYTES;
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if (SAGE_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (bit 32: timing probe, the tile is not waited for)
                     if ((SAGE_ABL & 4) == 0) __builtin_amdgcn_s_barrier();
                     if constexpr (HAS_DMA) {
                         // K: this wave's KP/4 pieces (1 KiB each, swizzled through the per-lane source offset); V: its VP/4 pieces.
