@@ -56,6 +56,9 @@
 #ifndef SAGE_DIAG_PIPE       // causal FP8 D = 128: a work item's last two tiles through the pipelined body (1) or as general iterations (0: A/B)
 #define SAGE_DIAG_PIPE 1
 #endif
+#ifndef SAGE_KARG_PREFETCH   // one scalar load per line of the parameter block at kernel entry (1) or not (0: A/B)
+#define SAGE_KARG_PREFETCH 1
+#endif
 #ifndef SAGE_TAIL_PIPE       // non-causal FP8: the last two whole tiles (+ a ragged one behind them) through the pipelined body (1) or as general iterations (0: A/B)
 #define SAGE_TAIL_PIPE 1
 #endif
@@ -164,6 +167,18 @@ sage_attn_kernel(const AttnParams p_arg)
     const kparams_t kp0 = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) AttnParams &p = *kp0;
     (void)p_arg;
+#if SAGE_KARG_PREFETCH
+    // The parameter block spans seven 64-byte lines and the prologue reads it in ten dependent rounds of scalar loads (branches in between): in a
+    // launch's first round of workgroups every first touch of a line is a miss of the scalar cache, three or four of them in series.  One load per
+    // line here, waited for together: one miss time instead, the rounds below hit.  (Values unused; each load has its own destination.)
+    static_assert(sizeof(AttnParams) > 0x180, "prefetch offsets lie inside the parameter block");
+    {
+        unsigned t0, t1, t2, t3, t4, t5, t6;
+        asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
+                     "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6) : "s"(kp0) : "memory");
+    }
+#endif
     using C = TileCfg<D, PV_FP8, NH>;
     constexpr int KT = C::KT;
     constexpr int NS = 2 * NH;                       // 32-key S^T sub-tiles per iteration
