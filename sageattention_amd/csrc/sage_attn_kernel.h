@@ -26,8 +26,12 @@
 //    K image is XOR-swizzled through the per-lane SOURCE address, the V image is pre-swizzled
 //    by the pre-pass: every MFMA operand read is a conflict-free ds_read_b128.
 //  * whole unmasked tiles run software-pipelined loops whose instruction order is pinned in asm (six bodies
-//    per trip: ring slot and score-register set are compile-time constants in each); the last two tiles of a
-//    work item and every masked / ragged tile run the general, phased iteration (tile_iter).
+//    per trip: ring slot and score-register set are compile-time constants in each).  A work item's last tiles
+//    -- the two diagonal tiles of a causal block, the last whole tiles and the ragged tile of a non-causal call --
+//    run the same body in three more KINDs behind the loop (nothing more requested, scores behind the diagonal or
+//    past Lk masked in front of the row maximum; DIAG_PIPE / TAIL_PIPE below say for which instantiations); what
+//    is left -- attn_mask variants, causal blocks ending in a partial tile, ragged FP16-PV tails, D = 64 FP16 PV,
+//    sequences under two tiles -- runs the general, phased iteration (tile_iter).
 //  * output tile is transposed through (now free) LDS and stored as whole rows, 16 B per lane.
 #pragma once
 #include "sage_common.h"
