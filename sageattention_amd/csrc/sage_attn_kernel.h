@@ -1038,7 +1038,7 @@ sage_attn_kernel(const AttnParams p_arg)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SAGE_TSTAMP(7);
     if (wave == 0 && p.trace != nullptr && bid < p.trace_wgs) {
-        if (lane < 8) p.trace[16 * bid + lane] = ttrace[lane];
+        if (lane < 8 || lane == 8 || lane >= 13) p.trace[16 * bid + lane] = ttrace[lane];
         if (lane == 9) p.trace[16 * bid + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
         if (lane == 10) p.trace[16 * bid + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
         if (lane == 11) p.trace[16 * bid + 11] = blockIdx.x;

@@ -322,6 +322,7 @@
                     static_assert(SIX_BODIES, "FP8 PV: both head sizes run the six-body loop");
                     const int left = n_steady - it;
                     int n6 = left / 6, r = left - 6 * n6;
+                    SAGE_TSTAMP(8);                  // (trace builds: first scores formed / six-body trips done / remainder done / last bodies done)
                     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 #pragma nounroll
                     for (; n6 > 0; n6--) {
@@ -330,6 +331,7 @@
                     }
                     // (the remainder body's per-lane LDS offsets are derived behind the six-body loop from a lane index the compiler cannot see
                     //  through: formed in front of it they would stay live across it, next to that loop's own -- registers D = 64 does not have)
+                    SAGE_TSTAMP(13);
                     int lane_r;                      // (v_mbcnt again rather than a copy of `lane`: nothing of the thread index has to live through the loop)
                     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_r));
                     const int n_r = lane_r & 31, g_r = lane_r >> 5;
@@ -343,6 +345,7 @@
                     // Causal: the work item's last two tiles (whole tiles both when exactly two are left: n_steady <= Lk / 64 - 2) keep the pipeline's
                     // order instead of draining it into two general iterations -- the scores of the first are in set A already, the last steady
                     // body requested the second.  Same arithmetic per score as a general tile's (bias subtraction + FMA against the same m): same bits.
+                    SAGE_TSTAMP(14);
                     // (the last bodies' per-lane offsets from a lane index of their own: shared with the remainder loop's they stay live across it)
                     int lane_t;
                     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
@@ -370,6 +373,7 @@
                             cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
                         }
                     }
+                    SAGE_TSTAMP(15);
                     n = n_t;                         // (what follows -- the drain's k scales, the general tiles -- reads the lane's row and half formed behind the loop)
                     g = g_t;
                 }
