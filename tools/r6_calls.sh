@@ -81,7 +81,7 @@ call13() {   # the round's record at the last kernel commit: whole GPU suite, PM
   out=gpurun_out/r6z; mkdir -p $out
   timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log; filter < $out/pytest.log | tail -6
   cp gpurun_out/parity_report.json $out/ 2>/dev/null
-  timeout 1800 python tools/pmc_collect.py r6z c3 c3f c2 c2r c2t c4 c4nc c5 c5f pp 2>&1 | filter | tee $out/pmc_summary.txt
+  SAGE_HEAD=${SAGE_HEAD:-$(cat .git_head 2>/dev/null)} timeout 1800 python tools/pmc_collect.py r6z c3 c3f c2 c2r c2t c4 c4nc c5 c5f pp 2>&1 | filter | tee $out/pmc_summary.txt
   cp $out/r6_pmc.json profiles/r6_pmc.json 2>/dev/null      # (so that the bench lines below carry this commit's traffic figures)
   TAG=r6z bash tools/final_round_runs.sh 2>&1 | filter | tail -40
 }
